@@ -1,0 +1,126 @@
+"""GPU parity of the implicit-GEMM kernels (conv2d / conv3d / linear; forward, data gradient,
+weight gradient) against torch's fp32 CPU convolution on the same inputs, through the C ABI.
+
+bf16 path with fp32 output: inputs are exactly representable in bf16 and the MFMA accumulates
+in fp32, so the tolerance is fp32-accumulation-order only (2e-4 relative to the output scale).
+fp32 path: 1e-5 relative.
+"""
+import zlib
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # name, N, D, H, W, Ci, Co, k(d,h,w), s, p
+    ("linear_small", 100, 1, 1, 1, 72, 40, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("linear_big", 300, 1, 1, 1, 512, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("linear_101", 37, 1, 1, 1, 256, 104, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("c2d_3x3_s1_p1", 3, 1, 13, 11, 16, 24, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("c2d_3x3_s2_p0", 2, 1, 27, 27, 32, 64, (1, 3, 3), (1, 2, 2), (0, 0, 0)),
+    ("c2d_5x5_s2_p0", 2, 1, 32, 30, 8, 32, (1, 5, 5), (1, 2, 2), (0, 0, 0)),
+    ("c2d_1x1_s2_p0", 2, 1, 14, 14, 64, 128, (1, 1, 1), (1, 2, 2), (0, 0, 0)),
+    ("c2d_7x7_s2_p3", 2, 1, 32, 32, 8, 64, (1, 7, 7), (1, 2, 2), (0, 3, 3)),
+    ("c2d_3x3_s2_p1", 2, 1, 28, 28, 128, 128, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    ("c2d_wide", 4, 1, 14, 14, 256, 264, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("c3d_3x3x3_p1", 2, 4, 10, 9, 8, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    ("c3d_3x3x3_p1_b", 1, 5, 7, 12, 32, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+]
+
+
+def _desc(N, D, H, W, Ci, Co, k, s, p):
+    Do = (D + 2 * p[0] - k[0]) // s[0] + 1
+    Ho = (H + 2 * p[1] - k[1]) // s[1] + 1
+    Wo = (W + 2 * p[2] - k[2]) // s[2] + 1
+    return [N, D, H, W, Ci, Do, Ho, Wo, Co, *k, *s, *p], (Do, Ho, Wo)
+
+
+def _to_ndhwc(t):
+    return t.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def _rel(a, b):
+    return (a - b).abs().max().item() / (b.abs().max().item() + 1e-12)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
+def test_conv_fwd_dgrad_wgrad(cuda, case, dt):
+    from video_classification_amd import _lib as L
+    name, N, D, H, W, Ci, Co, k, s, p = case
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
+    x = torch.randn(N, Ci, D, H, W, generator=g)
+    w = torch.randn(Co, Ci, *k, generator=g) * 0.1
+    b = torch.randn(Co, generator=g)
+    if dt == torch.bfloat16:
+        x = x.bfloat16().float()
+        w = w.bfloat16().float()
+    desc, (Do, Ho, Wo) = _desc(N, D, H, W, Ci, Co, k, s, p)
+    dy = torch.randn(N, Co, Do, Ho, Wo, generator=g)
+    if dt == torch.bfloat16:
+        dy = dy.bfloat16().float()
+
+    # CPU fp32 reference
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    yr = F.conv3d(xr, wr, b, stride=s, padding=p)
+    yr.backward(dy)
+
+    taps = k[0] * k[1] * k[2]
+    code = L.dtype_code(dt)
+    xd = _to_ndhwc(x).to(cuda, dt)
+    dyd = _to_ndhwc(dy).to(cuda, dt)
+    wd = w.reshape(Co, Ci, taps).contiguous().to(cuda)
+    bd = b.to(cuda)
+    wf = torch.empty(Co, taps, Ci, device=cuda, dtype=dt)
+    wt = torch.empty(Ci, taps, Co, device=cuda, dtype=dt)
+    L.call("vc_pack_weight", code, L.ptr(wd), L.ptr(wf), L.ptr(wt), Co, Ci, taps, Ci, Co, L.stream())
+    d = L.int_array(desc)
+
+    tol = 2e-4 if dt == torch.bfloat16 else 1e-5
+    # forward, fp32 output
+    y = torch.empty(N, Do, Ho, Wo, Co, device=cuda, dtype=torch.float32)
+    L.call("vc_conv_fwd", d, code, L.ptr(xd), L.ptr(wf), L.ptr(bd), L.ptr(y), 0, 0, 1, 0, L.stream())
+    torch.cuda.synchronize()
+    assert _rel(y.cpu(), _to_ndhwc(yr.detach())) < tol
+
+    # forward, compute-type output with ReLU
+    y2 = torch.empty(N, Do, Ho, Wo, Co, device=cuda, dtype=dt)
+    L.call("vc_conv_fwd", d, code, L.ptr(xd), L.ptr(wf), L.ptr(bd), L.ptr(y2), 0, 1, int(dt == torch.float32), 0,
+           L.stream())
+    torch.cuda.synchronize()
+    assert _rel(y2.float().cpu(), _to_ndhwc(yr.detach()).relu()) < (1e-2 if dt == torch.bfloat16 else tol)
+
+    # data gradient
+    dx = torch.empty(N, D, H, W, Ci, device=cuda, dtype=torch.float32)
+    L.call("vc_conv_dgrad", d, code, L.ptr(dyd), L.ptr(wt), L.ptr(dx), 0, 1, 0, L.stream())
+    torch.cuda.synchronize()
+    assert _rel(dx.cpu(), _to_ndhwc(xr.grad)) < tol
+
+    # weight gradient (MFMA path for bf16, naive path for fp32)
+    dwp = torch.zeros(Co, taps, Ci, device=cuda, dtype=torch.float32)
+    L.call("vc_conv_wgrad", d, code, L.ptr(xd), L.ptr(dyd), L.ptr(dwp), 0, L.stream())
+    dw = torch.empty(Co, Ci, taps, device=cuda, dtype=torch.float32)
+    L.call("vc_unpack_wgrad", L.ptr(dwp), L.ptr(dw), Co, Ci, taps, Ci, 0, L.stream())
+    torch.cuda.synchronize()
+    assert _rel(dw.cpu(), wr.grad.reshape(Co, Ci, taps)) < tol
+
+    if dt == torch.bfloat16:
+        # on-device cross-check: naive kernels on the same bf16 data
+        yn = torch.empty_like(y)
+        L.call("vc_conv_fwd_naive_bf16", d, 0, L.ptr(xd), L.ptr(wf), L.ptr(bd), L.ptr(yn), 0, 1, L.stream())
+        dwn = torch.zeros_like(dwp)
+        L.call("vc_conv_wgrad", d, code, L.ptr(xd), L.ptr(dyd), L.ptr(dwn), 1, L.stream())
+        torch.cuda.synchronize()
+        assert _rel(y, yn) < tol
+        assert _rel(dwp, dwn) < tol
+
+
+def test_bad_shape_is_reported(cuda):
+    from video_classification_amd import _lib as L
+    desc = L.int_array([1, 1, 8, 8, 8, 1, 5, 5, 8, 1, 3, 3, 1, 1, 1, 0, 0, 0])  # Ho should be 6
+    t = torch.zeros(8, device=cuda)
+    with pytest.raises(RuntimeError, match="output extent"):
+        L.call("vc_conv_fwd", desc, 1, L.ptr(t), L.ptr(t), L.ptr(None), L.ptr(t), 0, 0, 0, 0, L.stream())

@@ -1,0 +1,649 @@
+// Implicit-GEMM convolution / linear kernels for gfx950 (MI355X).
+//
+// One kernel family serves every dense contraction on the path: Conv2d, Conv3d and
+// Linear (a 1x1x1 convolution over a 1x1x1 image), forward, data-gradient and
+// weight-gradient.  Activations are NDHWC (channels innermost), weights are packed
+// [Cout][kd*kh*kw*Cin] with the tap index outside the channel index, so that every
+// 8-channel group is one 16-byte load.
+//
+//   * igemm_nt: out[pixel][co] = sum_k gather(src)[pixel][k] * wgt[co][k]
+//       MODE 0: forward gather (in = out*stride - pad + tap)
+//       MODE 1: data-gradient gather (in = (out + pad - tap)/stride when divisible)
+//     128x128x64 tiles, 4 waves (2x2), 4x4 v_mfma_f32_16x16x32_bf16 tiles per wave,
+//     register-staged global->LDS double buffering, XOR-swizzled 128-byte LDS rows.
+//   * igemm_tn (weight gradient): dw[co][k] += sum_pixel dy[pixel][co] * gather(x)[pixel][k]
+//     Both operands are pixel-major in memory, i.e. transposed with respect to what an
+//     MFMA fragment wants, so the LDS tiles stay pixel-major and the fragments are read
+//     with ds_read_b64_tr_b16 (the hardware transposing LDS read of gfx950).
+//     Split over the pixel dimension; partial tiles are combined with fp32 atomics.
+//   * naive kernels (any element type): one thread per output element, fp32 accumulate.
+//     They are the dtype = fp32 implementation (exact-order-independent fp32 reference
+//     grade) and the on-device cross-check for the MFMA kernels.
+#include "vc_common.h"
+
+namespace {
+
+constexpr int BM = 128;  // pixels per tile
+constexpr int BN = 128;  // output channels per tile
+constexpr int BK = 64;   // reduction elements per LDS stage
+constexpr int NTHR = 256;
+
+// ----------------------------------------------------------------------------
+// Pixel-row decode and gather addressing shared by all kernels.
+// ----------------------------------------------------------------------------
+struct RowPos {
+  int n, d0, h0, w0;  // MODE 0: od*sd-pd, ...   MODE 1: od+pd, ...
+};
+
+template <int MODE>
+__device__ __forceinline__ RowPos decode_row(const ConvGeom& g, int m) {
+  RowPos r;
+  if (m >= g.M) {
+    r.n = 0;
+    r.d0 = r.h0 = r.w0 = -(1 << 28);
+    return r;
+  }
+  int t, ow, oh, od;
+  fd_divmod(m, g.fWo, t, ow);
+  fd_divmod(t, g.fHo, t, oh);
+  fd_divmod(t, g.fDo, t, od);
+  r.n = t;
+  if (MODE == 0) {
+    r.d0 = od * g.sd - g.pd;
+    r.h0 = oh * g.sh - g.ph;
+    r.w0 = ow * g.sw - g.pw;
+  } else {
+    r.d0 = od + g.pd;
+    r.h0 = oh + g.ph;
+    r.w0 = ow + g.pw;
+  }
+  return r;
+}
+
+// Offset (in elements) of the source pixel for row r and tap (rd, rh, rw); -1 if the
+// tap falls outside the source (zero padding / no contributing output).
+template <int MODE>
+__device__ __forceinline__ int gather_pixel(const ConvGeom& g, const RowPos& r, int rd, int rh, int rw) {
+  int id, ih, iw;
+  if (MODE == 0) {
+    id = r.d0 + rd;
+    ih = r.h0 + rh;
+    iw = r.w0 + rw;
+    if ((unsigned)id >= (unsigned)g.Di || (unsigned)ih >= (unsigned)g.Hi || (unsigned)iw >= (unsigned)g.Wi) return -1;
+  } else {
+    const int td = r.d0 - rd, th = r.h0 - rh, tw = r.w0 - rw;
+    if ((td | th | tw) < 0) return -1;
+    if ((td & (g.sd - 1)) | (th & (g.sh - 1)) | (tw & (g.sw - 1))) return -1;
+    id = td >> (__builtin_ctz(g.sd));
+    ih = th >> (__builtin_ctz(g.sh));
+    iw = tw >> (__builtin_ctz(g.sw));
+    if (id >= g.Di || ih >= g.Hi || iw >= g.Wi) return -1;
+  }
+  return ((r.n * g.Di + id) * g.Hi + ih) * g.Wi + iw;
+}
+
+__device__ __forceinline__ void decode_chunk(const ConvGeom& g, int kc, int& rd, int& rh, int& rw, int& c) {
+  int tap, c8, t2;
+  fd_divmod(kc, g.fC8, tap, c8);
+  c = c8 * 8;
+  fd_divmod(tap, g.fkw, t2, rw);
+  fd_divmod(t2, g.fkh, rd, rh);
+}
+
+// ----------------------------------------------------------------------------
+// NT kernel (forward / data gradient / linear).
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ int nt_lds_off(int row, int chunk) {  // in elements
+  return row * BK + ((chunk ^ ((row >> 1) & 7)) << 3);
+}
+
+__device__ __forceinline__ void xcd_remap(int& logical) {
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
+  logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(NTHR, 2) void igemm_nt_bf16_kernel(ConvGeom g, const bf16* __restrict__ src,
+                                                                const bf16* __restrict__ wgt,
+                                                                const float* __restrict__ bias, void* __restrict__ out,
+                                                                int relu, int out_f32, int beta) {
+  __shared__ __attribute__((aligned(16))) bf16 smem[2 * (BM + BN) * BK];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = (g.Co + BN - 1) / BN;
+  int logical;
+  xcd_remap(logical);
+  const int tile_m = logical / tiles_n, tile_n = logical - tile_m * tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int lrow = tid >> 3, lchunk = tid & 7;
+  RowPos rp[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rp[i] = decode_row<MODE>(g, m0 + lrow + 32 * i);
+
+  const int nk = (g.K + BK - 1) / BK;
+  bf16x8 areg[4], wreg[4];
+
+  auto load_tile = [&](int kt) {
+    const int kc = kt * (BK / 8) + lchunk;
+    const bool kvalid = kc * 8 < g.K;
+    int rd, rh, rw, c;
+    decode_chunk(g, kc, rd, rh, rw, c);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      const int pix = gather_pixel<MODE>(g, rp[i], rd, rh, rw);
+      if (kvalid && pix >= 0) v = *reinterpret_cast<const bf16x8*>(src + (size_t)pix * g.Ci + c);
+      areg[i] = v;
+      bf16x8 w = {0, 0, 0, 0, 0, 0, 0, 0};
+      const int co = n0 + lrow + 32 * i;
+      if (kvalid && co < g.Co) w = *reinterpret_cast<const bf16x8*>(wgt + (size_t)co * g.K + kc * 8);
+      wreg[i] = w;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    bf16* sA = smem + buf * (BM + BN) * BK;
+    bf16* sW = sA + BM * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = lrow + 32 * i;
+      *reinterpret_cast<bf16x8*>(sA + nt_lds_off(row, lchunk)) = areg[i];
+      *reinterpret_cast<bf16x8*>(sW + nt_lds_off(row, lchunk)) = wreg[i];
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+    const bf16* sA = smem + buf * (BM + BN) * BK;
+    const bf16* sW = sA + BM * BK;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int chunk = ks * 4 + (lane >> 4);
+      bf16x8 wf[4], af[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        wf[i] = *reinterpret_cast<const bf16x8*>(sW + nt_lds_off(wn * 64 + i * 16 + (lane & 15), chunk));
+        af[i] = *reinterpret_cast<const bf16x8*>(sA + nt_lds_off(wm * 64 + i * 16 + (lane & 15), chunk));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // Epilogue: lane holds 4 consecutive channels of one pixel per 16x16 tile.
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = m0 + wm * 64 + j * 16 + (lane & 15);
+    if (m >= g.M) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int co = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
+      if (co >= g.Co) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
+      const size_t o = (size_t)m * g.ldc + co;
+      const bool full = (co + 3 < g.Co);
+      if (bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (co + r < g.Co) v[r] += bias[co + r];
+      }
+      if (out_f32) {
+        float* op = reinterpret_cast<float*>(out) + o;
+        if (beta) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (co + r < g.Co) v[r] += op[r];
+        }
+        if (relu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (full && ((g.ldc & 3) == 0)) {
+          *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (co + r < g.Co) op[r] = v[r];
+        }
+      } else {
+        bf16* op = reinterpret_cast<bf16*>(out) + o;
+        if (beta) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (co + r < g.Co) v[r] += (float)op[r];
+        }
+        if (relu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (full && ((g.ldc & 3) == 0)) {
+          *reinterpret_cast<bf16x4*>(op) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (co + r < g.Co) op[r] = (bf16)v[r];
+        }
+      }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------
+// TN kernel (weight gradient).  g is the FORWARD geometry (src = x).
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ int tn_swz(int row) { return (row & 3) | ((row >> 1) & 4); }
+// element offset of 16-byte chunk `chunk` (0..15) of pixel row `row` in a [64][128] tile
+__device__ __forceinline__ int tn_lds_off(int row, int chunk) {
+  return row * 128 + ((((chunk >> 1) ^ tn_swz(row)) << 1) | (chunk & 1)) * 8;
+}
+// element offset of the 8-byte piece p (0..3) of 16-column block `blk` (0..7) of row `row`
+__device__ __forceinline__ int tn_tr_off(int row, int blk, int p) {
+  return row * 128 + ((blk ^ tn_swz(row)) << 4) + p * 4;
+}
+
+__device__ __forceinline__ bf16x8 tr_read_frag(const bf16* tile, int krow0, int blk, int lane) {
+  // 16-lane group gq reads rows krow0 + 8*gq + {0..3} then + {4..7}; lane 4q+p of the
+  // group supplies row q, columns 4p..4p+3; lane i receives column i of those rows.
+  const int gq = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  const int r0 = krow0 + 8 * gq + q;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + tn_tr_off(r0, blk, p)));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + tn_tr_off(r0 + 4, blk, p)));
+  union {
+    struct {
+      s16x4 a, b;
+    } s;
+    bf16x8 v;
+  } u;
+  u.s.a = lo;
+  u.s.b = hi;
+  return u.v;
+}
+
+__global__ __launch_bounds__(NTHR, 2) void igemm_tn_wgrad_bf16_kernel(ConvGeom g, const bf16* __restrict__ x,
+                                                                      const bf16* __restrict__ dy, int ldy,
+                                                                      float* __restrict__ dw, int m_per_split,
+                                                                      int ntiles, int tiles_col) {
+  __shared__ __attribute__((aligned(16))) bf16 smem[2 * 2 * BK * 128];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wm = wave & 1;  // wn: co half, wm: col half
+  int logical;
+  xcd_remap(logical);
+  const int split = logical / ntiles, tile = logical - split * ntiles;
+  const int tile_co = tile / tiles_col, tile_col = tile - tile_co * tiles_col;
+  const int co0 = tile_co * 128, col0 = tile_col * 128;
+  const int m_begin = split * m_per_split;
+  const int m_end = min(g.M, m_begin + m_per_split);
+
+  const int lchunk = tid & 15, lrow = tid >> 4;
+  // this thread's gather column is fixed for the whole kernel
+  const int col = col0 + lchunk * 8;
+  const bool colvalid = col < g.K;
+  int rd, rh, rw, c;
+  decode_chunk(g, col >> 3, rd, rh, rw, c);
+  const int co_ld = co0 + lchunk * 8;
+  const bool covalid = co_ld < g.Co;
+
+  bf16x8 xreg[4], yreg[4];
+  auto load_tile = [&](int mt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = mt + lrow + 16 * i;
+      bf16x8 xv = {0, 0, 0, 0, 0, 0, 0, 0}, yv = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (m < m_end) {
+        if (covalid) yv = *reinterpret_cast<const bf16x8*>(dy + (size_t)m * ldy + co_ld);
+        if (colvalid) {
+          const RowPos rp = decode_row<0>(g, m);
+          const int pix = gather_pixel<0>(g, rp, rd, rh, rw);
+          if (pix >= 0) xv = *reinterpret_cast<const bf16x8*>(x + (size_t)pix * g.Ci + c);
+        }
+      }
+      xreg[i] = xv;
+      yreg[i] = yv;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    bf16* sY = smem + buf * (2 * BK * 128);
+    bf16* sX = sY + BK * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = lrow + 16 * i;
+      *reinterpret_cast<bf16x8*>(sY + tn_lds_off(row, lchunk)) = yreg[i];
+      *reinterpret_cast<bf16x8*>(sX + tn_lds_off(row, lchunk)) = xreg[i];
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (m_begin < m_end) {
+    load_tile(m_begin);
+    store_tile(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int mt = m_begin; mt < m_end; mt += BK) {
+    const bool more = mt + BK < m_end;
+    if (more) load_tile(mt + BK);
+    const bf16* sY = smem + buf * (2 * BK * 128);
+    const bf16* sX = sY + BK * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 yf[4], xf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        yf[i] = tr_read_frag(sY, ks * 32, wn * 4 + i, lane);
+        xf[i] = tr_read_frag(sX, ks * 32, wm * 4 + i, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = co0 + wn * 64 + i * 16 + (lane >> 4) * 4 + r;
+      if (co >= g.Co) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int cc = col0 + wm * 64 + j * 16 + (lane & 15);
+        if (cc < g.K) atomicAdd(dw + (size_t)co * g.K + cc, acc[i][j][r]);
+      }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------
+// Naive kernels (fp32 path and cross-check).
+// ----------------------------------------------------------------------------
+template <typename T, int MODE>
+__global__ void conv_naive_kernel(ConvGeom g, const T* __restrict__ src, const T* __restrict__ wgt,
+                                  const float* __restrict__ bias, void* __restrict__ out, int relu, int out_f32,
+                                  int beta) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)g.M * g.Co) return;
+  const int m = (int)(idx / g.Co), co = (int)(idx - (int64_t)m * g.Co);
+  const RowPos rp = decode_row<MODE>(g, m);
+  float acc = 0.f;
+  const T* wrow = wgt + (size_t)co * g.K;
+  int tap = 0;
+  for (int rd = 0; rd < g.kd; ++rd)
+    for (int rh = 0; rh < g.kh; ++rh)
+      for (int rw = 0; rw < g.kw; ++rw, ++tap) {
+        const int pix = gather_pixel<MODE>(g, rp, rd, rh, rw);
+        if (pix < 0) continue;
+        const T* sp = src + (size_t)pix * g.Ci;
+        const T* wp = wrow + (size_t)tap * g.Ci;
+        for (int c = 0; c < g.Ci; ++c) acc = fmaf(to_f32(sp[c]), to_f32(wp[c]), acc);
+      }
+  if (bias) acc += bias[co];
+  const size_t o = (size_t)m * g.ldc + co;
+  if (out_f32) {
+    float* op = reinterpret_cast<float*>(out);
+    if (beta) acc += op[o];
+    if (relu) acc = fmaxf(acc, 0.f);
+    op[o] = acc;
+  } else {
+    T* op = reinterpret_cast<T*>(out);
+    if (beta) acc += to_f32(op[o]);
+    if (relu) acc = fmaxf(acc, 0.f);
+    op[o] = from_f32<T>(acc);
+  }
+}
+
+template <typename T>
+__global__ void wgrad_naive_kernel(ConvGeom g, const T* __restrict__ x, const T* __restrict__ dy, int ldy,
+                                   float* __restrict__ dw) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)g.Co * g.K) return;
+  const int co = (int)(idx / g.K), kk = (int)(idx - (int64_t)co * g.K);
+  const int tap = kk / g.Ci, c = kk - tap * g.Ci;
+  const int rw = tap % g.kw, rh = (tap / g.kw) % g.kh, rd = tap / (g.kw * g.kh);
+  float acc = 0.f;
+  for (int m = 0; m < g.M; ++m) {
+    const RowPos rp = decode_row<0>(g, m);
+    const int pix = gather_pixel<0>(g, rp, rd, rh, rw);
+    if (pix < 0) continue;
+    acc = fmaf(to_f32(dy[(size_t)m * ldy + co]), to_f32(x[(size_t)pix * g.Ci + c]), acc);
+  }
+  dw[idx] += acc;
+}
+
+// ----------------------------------------------------------------------------
+// Weight packing: torch layout [Co][Ci][taps] fp32 <-> packed [Co][taps][Cip] (forward)
+// and [Ci][taps][Cop] (data gradient), in the compute type.
+// ----------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wt, int Co, int Ci,
+                                   int taps, int Cip, int Cop) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // forward pack: [Co][taps][Cip]
+  const int64_t nf = (int64_t)Co * taps * Cip;
+  if (wf && idx < nf) {
+    const int c = (int)(idx % Cip);
+    const int tap = (int)((idx / Cip) % taps);
+    const int co = (int)(idx / ((int64_t)Cip * taps));
+    wf[idx] = from_f32<T>(c < Ci ? w[((size_t)co * Ci + c) * taps + tap] : 0.f);
+  }
+  // transposed pack: [Ci][taps][Cop]
+  const int64_t nt = (int64_t)Ci * taps * Cop;
+  if (wt && idx < nt) {
+    const int co = (int)(idx % Cop);
+    const int tap = (int)((idx / Cop) % taps);
+    const int ci = (int)(idx / ((int64_t)Cop * taps));
+    wt[idx] = from_f32<T>(co < Co ? w[((size_t)co * Ci + ci) * taps + tap] : 0.f);
+  }
+}
+
+// packed fp32 gradient [Co][taps][Cip] -> torch layout [Co][Ci][taps] (accumulating or not)
+__global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Co, int Ci, int taps,
+                                    int Cip, int accumulate) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)Co * Ci * taps) return;
+  const int tap = (int)(idx % taps);
+  const int ci = (int)((idx / taps) % Ci);
+  const int co = (int)(idx / ((int64_t)taps * Ci));
+  const float v = dwp[((size_t)co * taps + tap) * Cip + ci];
+  dw[idx] = accumulate ? dw[idx] + v : v;
+}
+
+int fill_geom(ConvGeom& g, const int* d, int mode, const char* who) {
+  // d: n, di, hi, wi, ci, do, ho, wo, co, kd, kh, kw, sd, sh, sw, pd, ph, pw  (forward meaning)
+  const int n = d[0], di = d[1], hi = d[2], wi = d[3], ci = d[4], dout = d[5], ho = d[6], wo = d[7], co = d[8];
+  const int kd = d[9], kh = d[10], kw = d[11], sd = d[12], sh = d[13], sw = d[14], pd = d[15], ph = d[16], pw = d[17];
+  VC_CHECK_SHAPE(n > 0 && di > 0 && hi > 0 && wi > 0 && ci > 0 && dout > 0 && ho > 0 && wo > 0 && co > 0,
+                 "%s: non-positive extent", who);
+  VC_CHECK_SHAPE(kd > 0 && kh > 0 && kw > 0 && sd > 0 && sh > 0 && sw > 0 && pd >= 0 && ph >= 0 && pw >= 0,
+                 "%s: bad kernel/stride/pad", who);
+  VC_CHECK_SHAPE((di + 2 * pd - kd) / sd + 1 == dout && (hi + 2 * ph - kh) / sh + 1 == ho &&
+                     (wi + 2 * pw - kw) / sw + 1 == wo,
+                 "%s: output extent does not match input/kernel/stride/pad", who);
+  VC_CHECK_SHAPE((int64_t)n * di * hi * wi * ci < (1ll << 31) && (int64_t)n * dout * ho * wo * co < (1ll << 31),
+                 "%s: tensor exceeds 2^31 elements", who);
+  g.kd = kd; g.kh = kh; g.kw = kw;
+  g.sd = sd; g.sh = sh; g.sw = sw;
+  g.pd = pd; g.ph = ph; g.pw = pw;
+  g.N = n;
+  if (mode == 0) {  // forward (also the geometry the weight-gradient kernels use)
+    g.Di = di; g.Hi = hi; g.Wi = wi; g.Ci = ci;
+    g.Do = dout; g.Ho = ho; g.Wo = wo;
+    g.Co = co;
+  } else {  // data gradient: rows are dx pixels, source is dy
+    VC_CHECK_SHAPE((sd & (sd - 1)) == 0 && (sh & (sh - 1)) == 0 && (sw & (sw - 1)) == 0,
+                   "%s: data gradient needs power-of-two strides", who);
+    g.Di = dout; g.Hi = ho; g.Wi = wo; g.Ci = co;
+    g.Do = di; g.Ho = hi; g.Wo = wi;
+    g.Co = ci;
+  }
+  g.K = kd * kh * kw * g.Ci;
+  g.M = g.N * g.Do * g.Ho * g.Wo;
+  g.ldc = g.Co;
+  g.fWo = make_fastdiv(g.Wo);
+  g.fHo = make_fastdiv(g.Ho);
+  g.fDo = make_fastdiv(g.Do);
+  g.fC8 = make_fastdiv(g.Ci / 8 > 0 ? g.Ci / 8 : 1);
+  g.fkw = make_fastdiv(kw);
+  g.fkh = make_fastdiv(kh);
+  return VC_OK;
+}
+
+template <int MODE>
+int launch_nt(const ConvGeom& g, int dtype, const void* src, const void* wgt, const float* bias, void* out, int relu,
+              int out_f32, int beta, hipStream_t stream, const char* who) {
+  if (dtype == VC_BF16) {
+    VC_CHECK_SHAPE(g.Ci % 8 == 0, "%s: bf16 path needs source channels %% 8 == 0 (got %d)", who, g.Ci);
+    const int tiles = ceil_div(g.M, BM) * ceil_div(g.Co, BN);
+    hipLaunchKernelGGL((igemm_nt_bf16_kernel<MODE>), dim3(tiles), dim3(NTHR), 0, stream, g, (const bf16*)src,
+                       (const bf16*)wgt, bias, out, relu, out_f32, beta);
+  } else if (dtype == VC_F32) {
+    const int64_t total = (int64_t)g.M * g.Co;
+    hipLaunchKernelGGL((conv_naive_kernel<float, MODE>), dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, stream,
+                       g, (const float*)src, (const float*)wgt, bias, out, relu, 1, beta);
+  } else {
+    vc_set_error("%s: unsupported dtype %d", who, dtype);
+    return VC_ERR_DTYPE;
+  }
+  VC_LAUNCH_CHECK(who);
+  return VC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vc_conv_fwd(const int* desc, int dtype, const void* x, const void* w_packed, const float* bias, void* y, int ldy,
+                int relu, int out_f32, int beta, hipStream_t stream) {
+  ConvGeom g;
+  int rc = fill_geom(g, desc, 0, "vc_conv_fwd");
+  if (rc) return rc;
+  VC_CHECK_ARG(x && w_packed && y, "vc_conv_fwd: null pointer");
+  if (ldy > 0) g.ldc = ldy;
+  VC_CHECK_SHAPE(g.ldc >= g.Co, "vc_conv_fwd: ldy < Co");
+  return launch_nt<0>(g, dtype, x, w_packed, bias, y, relu, out_f32, beta, stream, "vc_conv_fwd");
+}
+
+int vc_conv_dgrad(const int* desc, int dtype, const void* dy, const void* w_packed_t, void* dx, int lddx, int out_f32,
+                  int beta, hipStream_t stream) {
+  ConvGeom g;
+  int rc = fill_geom(g, desc, 1, "vc_conv_dgrad");
+  if (rc) return rc;
+  VC_CHECK_ARG(dy && w_packed_t && dx, "vc_conv_dgrad: null pointer");
+  if (lddx > 0) g.ldc = lddx;
+  VC_CHECK_SHAPE(g.ldc >= g.Co, "vc_conv_dgrad: lddx < Ci");
+  return launch_nt<1>(g, dtype, dy, w_packed_t, nullptr, dx, 0, out_f32, beta, stream, "vc_conv_dgrad");
+}
+
+int vc_conv_wgrad(const int* desc, int dtype, const void* x, const void* dy, float* dw_packed, int force_naive,
+                  hipStream_t stream) {
+  ConvGeom g;
+  int rc = fill_geom(g, desc, 0, "vc_conv_wgrad");
+  if (rc) return rc;
+  VC_CHECK_ARG(x && dy && dw_packed, "vc_conv_wgrad: null pointer");
+  if (dtype == VC_BF16 && !force_naive) {
+    VC_CHECK_SHAPE(g.Ci % 8 == 0 && g.Co % 8 == 0, "vc_conv_wgrad: bf16 path needs Ci %% 8 == 0 and Co %% 8 == 0");
+    const int tiles_co = ceil_div(g.Co, 128), tiles_col = ceil_div(g.K, 128);
+    const int ntiles = tiles_co * tiles_col;
+    int splits = ceil_div(1024, ntiles);
+    const int max_splits = ceil_div(g.M, BK);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    int mps = ceil_div(ceil_div(g.M, splits), BK) * BK;
+    splits = ceil_div(g.M, mps);
+    hipLaunchKernelGGL(igemm_tn_wgrad_bf16_kernel, dim3(ntiles * splits), dim3(NTHR), 0, stream, g, (const bf16*)x,
+                       (const bf16*)dy, g.Co, dw_packed, mps, ntiles, tiles_col);
+  } else if (dtype == VC_BF16) {
+    const int64_t total = (int64_t)g.Co * g.K;
+    hipLaunchKernelGGL((wgrad_naive_kernel<bf16>), dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, stream, g,
+                       (const bf16*)x, (const bf16*)dy, g.Co, dw_packed);
+  } else if (dtype == VC_F32) {
+    const int64_t total = (int64_t)g.Co * g.K;
+    hipLaunchKernelGGL((wgrad_naive_kernel<float>), dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, stream, g,
+                       (const float*)x, (const float*)dy, g.Co, dw_packed);
+  } else {
+    vc_set_error("vc_conv_wgrad: unsupported dtype %d", dtype);
+    return VC_ERR_DTYPE;
+  }
+  VC_LAUNCH_CHECK("vc_conv_wgrad");
+  return VC_OK;
+}
+
+// Cross-check entry: the naive kernel on bf16 data (used by the tests to validate the MFMA path).
+int vc_conv_fwd_naive_bf16(const int* desc, int mode, const void* src, const void* w_packed, const float* bias,
+                           void* out, int relu, int out_f32, hipStream_t stream) {
+  ConvGeom g;
+  int rc = fill_geom(g, desc, mode, "vc_conv_fwd_naive_bf16");
+  if (rc) return rc;
+  const int64_t total = (int64_t)g.M * g.Co;
+  if (mode == 0)
+    hipLaunchKernelGGL((conv_naive_kernel<bf16, 0>), dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, stream, g,
+                       (const bf16*)src, (const bf16*)w_packed, bias, out, relu, out_f32, 0);
+  else
+    hipLaunchKernelGGL((conv_naive_kernel<bf16, 1>), dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, stream, g,
+                       (const bf16*)src, (const bf16*)w_packed, bias, out, relu, out_f32, 0);
+  VC_LAUNCH_CHECK("vc_conv_fwd_naive_bf16");
+  return VC_OK;
+}
+
+int vc_pack_weight(int dtype, const float* w, void* w_fwd, void* w_t, int co, int ci, int taps, int ci_pad, int co_pad,
+                   hipStream_t stream) {
+  VC_CHECK_ARG(w && (w_fwd || w_t), "vc_pack_weight: null pointer");
+  VC_CHECK_SHAPE(co > 0 && ci > 0 && taps > 0 && ci_pad >= ci && co_pad >= co, "vc_pack_weight: bad shape");
+  const int64_t nf = w_fwd ? (int64_t)co * taps * ci_pad : 0, nt = w_t ? (int64_t)ci * taps * co_pad : 0;
+  const int64_t total = nf > nt ? nf : nt;
+  if (dtype == VC_BF16)
+    hipLaunchKernelGGL((pack_weight_kernel<bf16>), dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, stream, w,
+                       (bf16*)w_fwd, (bf16*)w_t, co, ci, taps, ci_pad, co_pad);
+  else if (dtype == VC_F32)
+    hipLaunchKernelGGL((pack_weight_kernel<float>), dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, stream, w,
+                       (float*)w_fwd, (float*)w_t, co, ci, taps, ci_pad, co_pad);
+  else {
+    vc_set_error("vc_pack_weight: unsupported dtype %d", dtype);
+    return VC_ERR_DTYPE;
+  }
+  VC_LAUNCH_CHECK("vc_pack_weight");
+  return VC_OK;
+}
+
+int vc_unpack_wgrad(const float* dw_packed, float* dw, int co, int ci, int taps, int ci_pad, int accumulate,
+                    hipStream_t stream) {
+  VC_CHECK_ARG(dw_packed && dw, "vc_unpack_wgrad: null pointer");
+  const int64_t total = (int64_t)co * ci * taps;
+  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, stream, dw_packed, dw,
+                     co, ci, taps, ci_pad, accumulate);
+  VC_LAUNCH_CHECK("vc_unpack_wgrad");
+  return VC_OK;
+}
+
+}  // extern "C"
