@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Throughput benchmark of the hot path: train clips/sec on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on): ResNetCRNN =
+ResCNNEncoder (bottleneck ResNet-50 trunk, heads 1024/768/512) + DecoderRNN (2-layer LSTM, h=512, FC 256,
+101 classes), batch 32 clips per GPU of 16 x 3 x 224 x 224, bf16 compute with fp32 master weights, one
+full training step = forward + cross-entropy + backward + gradient all-reduce (N>1) + fused Adam.
+`--arch resnet152 --lstm-layers 3` selects what the reference's code actually instantiates.
+Clips are synthetic (randn, seed 1234+rank), weights are the modules' default initialisation
+(seed 0) and are resident in HBM before the timed region.  One rank per GPU, weak scaling (32 clips
+per GPU whatever N).
+
+The JSON line also carries
+  roofline     : the forward implicit-GEMM convolution kernel (the dominant kernel family) -- algorithmic
+                 FLOP/s (2*M*Cout*Cin*taps per launch, unpadded channels, summed over the launches of the
+                 timed region / their summed durations from HIP events on the launch stream) against the dense
+                 bf16 MFMA peak of 2.5 PFLOP/s.
+  cpu_baseline : the CPU oracle (oracle/torch_oracle.py, same architecture, fp32) timed on this host for a
+                 bounded sample (2 clips per step), rank 0 / N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X
+
+
+def model_config(args):
+    return types.SimpleNamespace(CNN_fc_hidden1=1024, CNN_fc_hidden2=768, CNN_embed_dim=512, dropout_p=args.dropout,
+                                 use_pretrained=False, RNN_hidden_layers=args.lstm_layers, RNN_hidden_nodes=512,
+                                 RNN_FC_dim=256, num_classes=101, arch=args.arch)
+
+
+def cpu_baseline(args):
+    """The oracle's training step on the host CPU, bounded sample."""
+    import torch.nn as nn
+    from oracle import torch_oracle as O
+    b = args.cpu_batch
+    torch.manual_seed(0)
+    model = O.ResNetCRNNModel(model_config(args))
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-4)
+    crit = nn.CrossEntropyLoss()
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(b, 16, 3, 224, 224, generator=g)
+    y = torch.randint(0, 101, (b, 1), generator=g)
+    O.train_step(model, x, y, crit, opt)  # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while n < args.cpu_steps:
+        O.train_step(model, x, y, crit, opt)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": b * n / dt, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} training steps of {b} clips (16x3x224x224) after 1 warm-up, fp32, same architecture"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
+    ap.add_argument("--arch", default="resnet50", choices=["resnet50", "resnet101", "resnet152"])
+    ap.add_argument("--lstm-layers", type=int, default=2)
+    ap.add_argument("--dropout", type=float, default=0.3, help="configs/ResNetCRNN_train.yaml model.dropout")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--bucket-mb", type=int, default=32)
+    args = ap.parse_args()
+
+    from video_classification_amd import modules as M
+    from video_classification_amd import ops
+    from video_classification_amd import trainer as TR
+
+    rank, local_rank, world = TR.init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; the HIP path has no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.manual_seed(0)
+    model = M.ResNetCRNNModel(model_config(args)).to(dev).set_compute_dtype(dt)
+    opt = TR.get_optimizer(model, "adam", lr=1e-4, weight_decay=1e-4)
+    TR.make_data_parallel(model, opt, bucket_mb=args.bucket_mb)
+    crit = TR.FusedCrossEntropyLoss()
+    ops.manual_seed(1234 + rank)
+    g = torch.Generator().manual_seed(1234 + rank)
+    B = args.batch
+    x = torch.randn(B, 16, 3, 224, 224, generator=g).to(dev)
+    y = torch.randint(0, 101, (B, 1), generator=g).to(dev)
+    model.train()
+
+    def step():
+        opt.zero_grad()
+        out = model(x)
+        loss = crit(out, y)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    ops.PROFILE = []
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    # per-kernel-family time from the HIP events recorded around each contraction launch
+    fam = {}
+    for tag, flops, s, e in prof:
+        f = fam.setdefault(tag, [0.0, 0.0, 0])
+        f[0] += flops
+        f[1] += s.elapsed_time(e) * 1e-3
+        f[2] += 1
+    roof = None
+    if "conv_fwd" in fam and fam["conv_fwd"][1] > 0:
+        fl, tm, n = fam["conv_fwd"]
+        ach = fl / tm / 1e12
+        roof = {"bound": "mfma", "kernel": "igemm_nt_bf16_kernel<0> (forward conv/linear)", "achieved": ach,
+                "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                "launches": n, "avg_launch_ms": tm / n * 1e3, "avg_launch_gflop": fl / n / 1e9,
+                "other_kernels": {k: {"achieved_tflops": v[0] / v[1] / 1e12, "launches": v[2],
+                                      "ms_per_step": v[1] / args.steps * 1e3}
+                                  for k, v in fam.items() if v[1] > 0}}
+
+    if rank == 0:
+        line = {
+            "metric": "train clips/sec (16x224^2 UCF101 shape)",
+            "value": world * B * args.steps / elapsed,
+            "unit": "clips/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": f"ResNetCRNN training step: ResCNNEncoder({args.arch}, 1024/768/512) + DecoderRNN("
+                                   f"{args.lstm_layers}x512 LSTM, FC 256, 101 classes), {B} clips/GPU x 16 x 3 x 224 x 224, "
+                                   f"dropout {args.dropout}, fwd+CE+bwd+all-reduce+Adam",
+                       "global_batch": world * B, "frames_per_clip": 16, "parallelism": f"dp{world}"},
+            "loss": float(loss),
+            "roofline": roof,
+            "cpu_baseline": None,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,148 @@
+/* C ABI of libvc_hip.so -- hand-written gfx950 (MI355X) kernels for the video-classification hot path.
+ *
+ * The reference (paci12/video-classification) has no FFI: its boundary is the Python nn.Module API and
+ * everything underneath is stock torch.nn.  Each entry point below therefore names the torch operator
+ * call site in the reference that it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - Plain pointers and sizes only; every pointer is DEVICE memory owned by the caller (in practice a
+ *     torch tensor's data_ptr()).  The library never allocates or frees device memory.
+ *   - Every call enqueues work on `stream` and returns immediately; buffers must stay alive until the
+ *     stream reaches the call.  Calls are re-entrant per stream; the only library state is the
+ *     thread-local error string.
+ *   - Return value: 0 on success, negative vc status otherwise (VC_ERR_SHAPE -1, VC_ERR_DTYPE -2,
+ *     VC_ERR_HIP -3, VC_ERR_ARG -4); vc_last_error() then describes the failure.  Nothing is thrown.
+ *   - dtype: VC_F32 (0) = exact fp32 path (plain FMA kernels), VC_BF16 (1) = bf16 storage, MFMA with
+ *     fp32 accumulation.  Activations are channels-last: [N][D][H][W][C] (convolutions) or [M][C]
+ *     (linear), C a multiple of 8.
+ *   - Convolution descriptor `desc` = 18 ints:
+ *       n, di, hi, wi, ci,  do, ho, wo, co,  kd, kh, kw,  sd, sh, sw,  pd, ph, pw
+ *     with ci / co the PHYSICAL (padded) channel counts of x / y.  A Linear layer is the descriptor
+ *     {M,1,1,1,K, 1,1,1,N, 1,1,1, 1,1,1, 0,0,0}.
+ *   - Packed weights: forward [co][taps][ci], data-gradient [ci_true][taps][co]; taps = kd*kh*kw with
+ *     kw fastest.  vc_pack_weight produces both from the torch layout [Co][Ci][taps] (fp32).
+ */
+#ifndef VC_HIP_H
+#define VC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* vc_stream_t; /* hipStream_t */
+
+#define VC_F32 0
+#define VC_BF16 1
+
+/* ---- library ---- */
+int vc_version(void);
+const char* vc_last_error(void);
+
+/* ---- dense contractions (MFMA implicit GEMM) ------------------------------------------------------
+ * Replace nn.Conv2d (utils/common/model_components.py:91,96,101,106; torchvision ResNet convs behind
+ * :159-165), nn.Conv3d (models/Conv3D/UCF101_3DCNN_refactored.py:66,72,78,84), nn.Linear
+ * (model_components.py:110,114,115,166-170,216-217,273-277,425,484-489; Conv3D :96,99) and the
+ * gate products inside nn.LSTM (:209-214, 482-483), forward and backward.
+ * ld* = 0 means dense rows.  beta != 0 adds the result to what `y`/`dx` already hold. */
+int vc_conv_fwd(const int* desc, int dtype, const void* x, int ldx, const void* w_packed, const float* bias, void* y,
+                int ldy, int relu, int out_f32, int beta, vc_stream_t stream);
+int vc_conv_dgrad(const int* desc, int dtype, const void* dy, int lddy, const void* w_packed_t, void* dx, int lddx,
+                  int out_f32, int beta, vc_stream_t stream);
+/* dw_packed (fp32 [co][taps][ci]) is accumulated into with atomics: the caller zeroes it. */
+int vc_conv_wgrad(const int* desc, int dtype, const void* x, int ldx, const void* dy, int lddy, float* dw_packed,
+                  int force_naive, vc_stream_t stream);
+/* cross-check used by the tests: the plain-FMA kernel on bf16 data (mode 0 forward, 1 data gradient) */
+int vc_conv_fwd_naive_bf16(const int* desc, int mode, const void* src, const void* w_packed, const float* bias,
+                           void* out, int relu, int out_f32, vc_stream_t stream);
+int vc_pack_weight(int dtype, const float* w, void* w_fwd, void* w_t, int co, int ci, int taps, int ci_pad, int co_pad,
+                   vc_stream_t stream);
+int vc_unpack_wgrad(const float* dw_packed, float* dw, int co, int ci, int taps, int ci_pad, int accumulate,
+                    vc_stream_t stream);
+
+/* ---- BatchNorm with per-group statistics / LayerNorm ----------------------------------------------
+ * Replace nn.BatchNorm2d(momentum=0.01) (model_components.py:92,97,102,107), nn.BatchNorm1d(momentum=0.01)
+ * (:167,169,274,276), torchvision's BatchNorm2d, nn.BatchNorm3d (Conv3D :67,73,79,85) and the ReLU /
+ * residual add that follow them.  Rows are [G groups][rpg rows][C]; G = T reproduces the reference's
+ * per-time-step statistics and its T ordered running-stat updates (encoder loops at :119, :174, :281).
+ * sum/sumsq/s1/s2 are [G][C] fp32 accumulated with atomics: the caller zeroes them. */
+int vc_bn_stats(int dtype, const void* y, float* sum, float* sumsq, int G, int rpg, int C, vc_stream_t stream);
+int vc_bn_finalize(const float* sum, const float* sumsq, const float* gamma, const float* beta, float* running_mean,
+                   float* running_var, float* mean, float* invstd, float* scale, float* shift, int G, int C, int rpg,
+                   float eps, float momentum, int update_running, vc_stream_t stream);
+int vc_bn_eval_params(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                      float* scale, float* shift, int C, float eps, vc_stream_t stream);
+int vc_bn_apply(int dtype, const void* y, const float* scale, const float* shift, const void* residual, void* out,
+                int G, int rpg, int C, int relu, vc_stream_t stream);
+int vc_bn_bwd_reduce(int dtype, const void* y, const void* dout, const void* act, const float* mean,
+                     const float* invstd, float* s1, float* s2, int G, int rpg, int C, int relu, vc_stream_t stream);
+int vc_bn_bwd_apply(int dtype, const void* y, const void* dout, const void* act, const float* mean,
+                    const float* invstd, const float* scale, const float* s1, const float* s2, void* dy, void* dres,
+                    int G, int rpg, int C, int relu, vc_stream_t stream);
+int vc_bn_bwd_params(const float* s1, const float* s2, float* dgamma, float* dbeta, int G, int C, int accumulate,
+                     vc_stream_t stream);
+/* nn.LayerNorm inside the Swin-T backbone (timm, created at model_components.py:254, 412) */
+int vc_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* out, float* mean,
+                     float* rstd, int M, int C, float eps, vc_stream_t stream);
+int vc_layernorm_bwd(int dtype, const void* x, const void* dout, const float* gamma, const float* mean,
+                     const float* rstd, void* dx, float* dgamma, float* dbeta, int M, int C, vc_stream_t stream);
+
+/* ---- layout, pooling, elementwise ------------------------------------------------------------------ */
+/* x_3d[:, t] slicing + NCHW->channels-last (model_components.py:127, 176, 285, 460; Conv3D input
+ * [B,1,T,H,W] from utils/common/data_loaders.py:56).  time_major: frame = t*B + b. */
+int vc_clip_to_channels_last(int dtype, const float* x, void* out, int B, int T, int C, int S, int Cp,
+                             int time_major, int chan_outer, vc_stream_t stream);
+/* nn.MaxPool2d(3,2,1) of the ResNet stem; nn.MaxPool3d((1,2,2)) (Conv3D :69,75,81,87) as a per-frame 2-D pool */
+int vc_maxpool2d_fwd(int dtype, const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, int k, int s, int p,
+                     vc_stream_t stream);
+int vc_maxpool2d_bwd(int dtype, const void* dy, const uint8_t* idx, void* dx, int N, int H, int W, int C, int k, int s,
+                     int p, vc_stream_t stream);
+/* nn.AdaptiveAvgPool2d((1,1)) of ResNet, nn.AdaptiveAvgPool3d((1,1,1)) (Conv3D :90), Swin's token mean */
+int vc_avgpool_fwd(int dtype, const void* x, void* y, int N, int S, int C, vc_stream_t stream);
+int vc_avgpool_bwd(int dtype, const void* dy, void* dx, int N, int S, int C, vc_stream_t stream);
+/* op: 0 a+b, 1 a*(b>0) (F.relu backward), 2 relu(a), 3 gelu(a), 4 a*gelu'(b), 5 sigmoid(a) */
+int vc_elementwise(int dtype, int op, const void* a, const void* b, void* out, int64_t n, vc_stream_t stream);
+int vc_cast(int src_dtype, int dst_dtype, const void* a, void* out, int64_t n, vc_stream_t stream);
+/* bias gradients: out[c] += sum_m a[m][c] */
+int vc_colsum(int dtype, const void* a, float* out, int M, int C, int lda, vc_stream_t stream);
+/* F.dropout (model_components.py:136,184,228,297,302), nn.Dropout (Conv3D :95,98; TCG_LSTM :488) */
+int vc_dropout_fwd(int dtype, const void* x, void* out, uint8_t* mask, int64_t n, float p, uint64_t seed,
+                   vc_stream_t stream);
+int vc_dropout_bwd(int dtype, const void* dy, const uint8_t* mask, void* dx, int64_t n, float p, vc_stream_t stream);
+
+/* ---- LSTM cell (gate order i,f,g,o; nn.LSTM at model_components.py:209-214, 482-483) -------------- */
+int vc_lstm_cell_fwd(int dtype, const float* gates_x, int ldx, const float* gates_h, const float* c_prev, void* h_out,
+                     int ldh, float* c_out, float* act_out, int B, int H, vc_stream_t stream);
+int vc_lstm_cell_bwd(int dtype, const void* dh_out, int ldo, const float* dh_rec, const float* dc_next,
+                     const float* act, const float* c, const float* c_prev, void* dgates, float* dc_prev, int B, int H,
+                     vc_stream_t stream);
+
+/* ---- TCG-LSTM fusion (model_components.py:494-514) ------------------------------------------------- */
+int vc_tcg_inputs(int dtype, const float* g, const float* c, void* short_in, void* long_in, int B, int T, int Tl,
+                  int K, int E, int down, vc_stream_t stream);
+int vc_tcg_inputs_bwd(int dtype, const void* dshort, const void* dlong, float* dg, float* dc, int B, int T, int Tl,
+                      int K, int E, int down, vc_stream_t stream);
+int vc_tcg_prep(int dtype, const void* hs, const void* hl, void* cat, int T, int Tl, int B, int H, vc_stream_t stream);
+int vc_tcg_fuse_fwd(int dtype, const float* z, const void* cat, float* gate, float* h, float* alpha, void* clip,
+                    int T, int B, int H, vc_stream_t stream);
+int vc_tcg_fuse_bwd(int dtype, const void* dclip, const void* cat, const float* gate, const float* h,
+                    const float* alpha, void* dz, float* dhs, float* dup2, int T, int B, int H, vc_stream_t stream);
+int vc_tcg_combine_bwd(int dtype, const void* dcat, const float* dhs, const float* dup2, void* dhs_out, void* dhl,
+                       int T, int Tl, int B, int H, vc_stream_t stream);
+
+/* ---- loss and optimizer ----------------------------------------------------------------------------
+ * nn.CrossEntropyLoss + argmax + eq().sum() (train.py:554; utils/common/training_utils.py:85, 90-91);
+ * loss[0] and correct[0] are accumulated into: the caller zeroes them. */
+int vc_ce_fwd_bwd(int grad_dtype, const float* logits, int ld, const int64_t* target, float* loss, int64_t* pred,
+                  int* correct, void* dlogits, int ldd, int B, int C, float loss_scale, float grad_scale,
+                  vc_stream_t stream);
+/* optim.Adam (L2-coupled) / AdamW / SGD(momentum) (training_utils.py:324-329) over one flat fp32 buffer.
+ * mode 0 Adam, 1 AdamW, 2 SGD (b1 = momentum).  grad_scale folds the 1/world of the all-reduce. */
+int vc_optim_step(int mode, float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
+                  float eps, float wd, int step, float grad_scale, vc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VC_HIP_H */

@@ -40,3 +40,29 @@ def max_rel(a, b):
     a = torch.as_tensor(a).double()
     b = torch.as_tensor(b).double()
     return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def l2_rel(a, b):
+    a = torch.as_tensor(a).double()
+    b = torch.as_tensor(b).double()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def check_grads(named_params, grefs, tol, cancelled=()):
+    """Compare parameter gradients with the reference's.
+
+    tol bounds both the max-norm error (relative to the tensor's largest magnitude, at 3x tol) and the L2
+    error (relative to the tensor's norm, at tol).  `cancelled` lists biases that feed straight into a
+    BatchNorm: their true gradient is exactly zero (the mean subtraction cancels them), both sides only
+    hold rounding noise there, so they are bounded against the gradient scale of the layer's weight."""
+    for k, gref in grefs.items():
+        g = named_params[k].grad
+        assert g is not None, k
+        g = g.detach().cpu()
+        if any(k.endswith(c) for c in cancelled):
+            wkey = k[:-len("bias")] + "weight"
+            bound = tol * torch.as_tensor(grefs[wkey]).abs().max().item()
+            assert g.abs().max().item() <= bound, (k, g.abs().max().item(), bound)
+            continue
+        assert l2_rel(g, gref) < tol, (k, "l2", l2_rel(g, gref))
+        assert max_rel(g, gref) < 3 * tol, (k, "max", max_rel(g, gref))

@@ -82,26 +82,26 @@ def test_conv_fwd_dgrad_wgrad(cuda, case, dt):
     tol = 2e-4 if dt == torch.bfloat16 else 1e-5
     # forward, fp32 output
     y = torch.empty(N, Do, Ho, Wo, Co, device=cuda, dtype=torch.float32)
-    L.call("vc_conv_fwd", d, code, L.ptr(xd), L.ptr(wf), L.ptr(bd), L.ptr(y), 0, 0, 1, 0, L.stream())
+    L.call("vc_conv_fwd", d, code, L.ptr(xd), 0, L.ptr(wf), L.ptr(bd), L.ptr(y), 0, 0, 1, 0, L.stream())
     torch.cuda.synchronize()
     assert _rel(y.cpu(), _to_ndhwc(yr.detach())) < tol
 
     # forward, compute-type output with ReLU
     y2 = torch.empty(N, Do, Ho, Wo, Co, device=cuda, dtype=dt)
-    L.call("vc_conv_fwd", d, code, L.ptr(xd), L.ptr(wf), L.ptr(bd), L.ptr(y2), 0, 1, int(dt == torch.float32), 0,
+    L.call("vc_conv_fwd", d, code, L.ptr(xd), 0, L.ptr(wf), L.ptr(bd), L.ptr(y2), 0, 1, int(dt == torch.float32), 0,
            L.stream())
     torch.cuda.synchronize()
     assert _rel(y2.float().cpu(), _to_ndhwc(yr.detach()).relu()) < (1e-2 if dt == torch.bfloat16 else tol)
 
     # data gradient
     dx = torch.empty(N, D, H, W, Ci, device=cuda, dtype=torch.float32)
-    L.call("vc_conv_dgrad", d, code, L.ptr(dyd), L.ptr(wt), L.ptr(dx), 0, 1, 0, L.stream())
+    L.call("vc_conv_dgrad", d, code, L.ptr(dyd), 0, L.ptr(wt), L.ptr(dx), 0, 1, 0, L.stream())
     torch.cuda.synchronize()
     assert _rel(dx.cpu(), _to_ndhwc(xr.grad)) < tol
 
     # weight gradient (MFMA path for bf16, naive path for fp32)
     dwp = torch.zeros(Co, taps, Ci, device=cuda, dtype=torch.float32)
-    L.call("vc_conv_wgrad", d, code, L.ptr(xd), L.ptr(dyd), L.ptr(dwp), 0, L.stream())
+    L.call("vc_conv_wgrad", d, code, L.ptr(xd), 0, L.ptr(dyd), 0, L.ptr(dwp), 0, L.stream())
     dw = torch.empty(Co, Ci, taps, device=cuda, dtype=torch.float32)
     L.call("vc_unpack_wgrad", L.ptr(dwp), L.ptr(dw), Co, Ci, taps, Ci, 0, L.stream())
     torch.cuda.synchronize()
@@ -112,7 +112,7 @@ def test_conv_fwd_dgrad_wgrad(cuda, case, dt):
         yn = torch.empty_like(y)
         L.call("vc_conv_fwd_naive_bf16", d, 0, L.ptr(xd), L.ptr(wf), L.ptr(bd), L.ptr(yn), 0, 1, L.stream())
         dwn = torch.zeros_like(dwp)
-        L.call("vc_conv_wgrad", d, code, L.ptr(xd), L.ptr(dyd), L.ptr(dwn), 1, L.stream())
+        L.call("vc_conv_wgrad", d, code, L.ptr(xd), 0, L.ptr(dyd), 0, L.ptr(dwn), 1, L.stream())
         torch.cuda.synchronize()
         assert _rel(y, yn) < tol
         assert _rel(dwp, dwn) < tol
@@ -123,4 +123,4 @@ def test_bad_shape_is_reported(cuda):
     desc = L.int_array([1, 1, 8, 8, 8, 1, 5, 5, 8, 1, 3, 3, 1, 1, 1, 0, 0, 0])  # Ho should be 6
     t = torch.zeros(8, device=cuda)
     with pytest.raises(RuntimeError, match="output extent"):
-        L.call("vc_conv_fwd", desc, 1, L.ptr(t), L.ptr(t), L.ptr(None), L.ptr(t), 0, 0, 0, 0, L.stream())
+        L.call("vc_conv_fwd", desc, 1, L.ptr(t), 0, L.ptr(t), L.ptr(None), L.ptr(t), 0, 0, 0, 0, L.stream())

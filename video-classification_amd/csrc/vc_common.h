@@ -169,6 +169,7 @@ struct ConvGeom {
   int K;    // kd*kh*kw*Ci
   int M;    // N*Do*Ho*Wo
   int ldc;  // row stride of the output matrix, in elements
+  int ldi;  // row (pixel) stride of the gather source, in elements (>= Ci)
   FastDiv fWo, fHo, fDo;  // pixel index -> (n, od, oh, ow)
   FastDiv fC8, fkw, fkh;  // k-chunk index -> (tap, c) -> (rd, rh, rw)
 };

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_bf16_kernel(ConvGeom g, cons
     for (int i = 0; i < 4; ++i) {
       bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
       const int pix = gather_pixel<MODE>(g, rp[i], rd, rh, rw);
-      if (kvalid && pix >= 0) v = *reinterpret_cast<const bf16x8*>(src + (size_t)pix * g.Ci + c);
+      if (kvalid && pix >= 0) v = *reinterpret_cast<const bf16x8*>(src + (size_t)pix * g.ldi + c);
       areg[i] = v;
       bf16x8 w = {0, 0, 0, 0, 0, 0, 0, 0};
       const int co = n0 + lrow + 32 * i;
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_tn_wgrad_bf16_kernel(ConvGeom g
         if (colvalid) {
           const RowPos rp = decode_row<0>(g, m);
           const int pix = gather_pixel<0>(g, rp, rd, rh, rw);
-          if (pix >= 0) xv = *reinterpret_cast<const bf16x8*>(x + (size_t)pix * g.Ci + c);
+          if (pix >= 0) xv = *reinterpret_cast<const bf16x8*>(x + (size_t)pix * g.ldi + c);
         }
       }
       xreg[i] = xv;
@@ -404,7 +404,7 @@ __global__ void conv_naive_kernel(ConvGeom g, const T* __restrict__ src, const T
       for (int rw = 0; rw < g.kw; ++rw, ++tap) {
         const int pix = gather_pixel<MODE>(g, rp, rd, rh, rw);
         if (pix < 0) continue;
-        const T* sp = src + (size_t)pix * g.Ci;
+        const T* sp = src + (size_t)pix * g.ldi;
         const T* wp = wrow + (size_t)tap * g.Ci;
         for (int c = 0; c < g.Ci; ++c) acc = fmaf(to_f32(sp[c]), to_f32(wp[c]), acc);
       }
@@ -436,7 +436,7 @@ __global__ void wgrad_naive_kernel(ConvGeom g, const T* __restrict__ x, const T*
     const RowPos rp = decode_row<0>(g, m);
     const int pix = gather_pixel<0>(g, rp, rd, rh, rw);
     if (pix < 0) continue;
-    acc = fmaf(to_f32(dy[(size_t)m * ldy + co]), to_f32(x[(size_t)pix * g.Ci + c]), acc);
+    acc = fmaf(to_f32(dy[(size_t)m * ldy + co]), to_f32(x[(size_t)pix * g.ldi + c]), acc);
   }
   dw[idx] += acc;
 }
@@ -510,6 +510,7 @@ int fill_geom(ConvGeom& g, const int* d, int mode, const char* who) {
   g.K = kd * kh * kw * g.Ci;
   g.M = g.N * g.Do * g.Ho * g.Wo;
   g.ldc = g.Co;
+  g.ldi = g.Ci;
   g.fWo = make_fastdiv(g.Wo);
   g.fHo = make_fastdiv(g.Ho);
   g.fDo = make_fastdiv(g.Do);
@@ -543,34 +544,42 @@ int launch_nt(const ConvGeom& g, int dtype, const void* src, const void* wgt, co
 
 extern "C" {
 
-int vc_conv_fwd(const int* desc, int dtype, const void* x, const void* w_packed, const float* bias, void* y, int ldy,
-                int relu, int out_f32, int beta, hipStream_t stream) {
+int vc_conv_fwd(const int* desc, int dtype, const void* x, int ldx, const void* w_packed, const float* bias, void* y,
+                int ldy, int relu, int out_f32, int beta, hipStream_t stream) {
   ConvGeom g;
   int rc = fill_geom(g, desc, 0, "vc_conv_fwd");
   if (rc) return rc;
   VC_CHECK_ARG(x && w_packed && y, "vc_conv_fwd: null pointer");
   if (ldy > 0) g.ldc = ldy;
-  VC_CHECK_SHAPE(g.ldc >= g.Co, "vc_conv_fwd: ldy < Co");
+  if (ldx > 0) g.ldi = ldx;
+  VC_CHECK_SHAPE(g.ldc >= g.Co && g.ldi >= g.Ci, "vc_conv_fwd: leading dimension smaller than channel count");
+  VC_CHECK_SHAPE(dtype != VC_BF16 || g.ldi % 8 == 0, "vc_conv_fwd: bf16 path needs ldx %% 8 == 0");
   return launch_nt<0>(g, dtype, x, w_packed, bias, y, relu, out_f32, beta, stream, "vc_conv_fwd");
 }
 
-int vc_conv_dgrad(const int* desc, int dtype, const void* dy, const void* w_packed_t, void* dx, int lddx, int out_f32,
-                  int beta, hipStream_t stream) {
+int vc_conv_dgrad(const int* desc, int dtype, const void* dy, int lddy, const void* w_packed_t, void* dx, int lddx,
+                  int out_f32, int beta, hipStream_t stream) {
   ConvGeom g;
   int rc = fill_geom(g, desc, 1, "vc_conv_dgrad");
   if (rc) return rc;
   VC_CHECK_ARG(dy && w_packed_t && dx, "vc_conv_dgrad: null pointer");
   if (lddx > 0) g.ldc = lddx;
-  VC_CHECK_SHAPE(g.ldc >= g.Co, "vc_conv_dgrad: lddx < Ci");
+  if (lddy > 0) g.ldi = lddy;
+  VC_CHECK_SHAPE(g.ldc >= g.Co && g.ldi >= g.Ci, "vc_conv_dgrad: leading dimension smaller than channel count");
+  VC_CHECK_SHAPE(dtype != VC_BF16 || g.ldi % 8 == 0, "vc_conv_dgrad: bf16 path needs lddy %% 8 == 0");
   return launch_nt<1>(g, dtype, dy, w_packed_t, nullptr, dx, 0, out_f32, beta, stream, "vc_conv_dgrad");
 }
 
-int vc_conv_wgrad(const int* desc, int dtype, const void* x, const void* dy, float* dw_packed, int force_naive,
-                  hipStream_t stream) {
+int vc_conv_wgrad(const int* desc, int dtype, const void* x, int ldx, const void* dy, int lddy, float* dw_packed,
+                  int force_naive, hipStream_t stream) {
   ConvGeom g;
   int rc = fill_geom(g, desc, 0, "vc_conv_wgrad");
   if (rc) return rc;
   VC_CHECK_ARG(x && dy && dw_packed, "vc_conv_wgrad: null pointer");
+  if (ldx > 0) g.ldi = ldx;
+  const int ldy_ = lddy > 0 ? lddy : g.Co;
+  VC_CHECK_SHAPE(g.ldi >= g.Ci && ldy_ >= g.Co, "vc_conv_wgrad: leading dimension smaller than channel count");
+  VC_CHECK_SHAPE(dtype != VC_BF16 || (g.ldi % 8 == 0 && ldy_ % 8 == 0), "vc_conv_wgrad: bf16 path needs ld %% 8 == 0");
   if (dtype == VC_BF16 && !force_naive) {
     VC_CHECK_SHAPE(g.Ci % 8 == 0 && g.Co % 8 == 0, "vc_conv_wgrad: bf16 path needs Ci %% 8 == 0 and Co %% 8 == 0");
     const int tiles_co = ceil_div(g.Co, 128), tiles_col = ceil_div(g.K, 128);
@@ -582,15 +591,15 @@ int vc_conv_wgrad(const int* desc, int dtype, const void* x, const void* dy, flo
     int mps = ceil_div(ceil_div(g.M, splits), BK) * BK;
     splits = ceil_div(g.M, mps);
     hipLaunchKernelGGL(igemm_tn_wgrad_bf16_kernel, dim3(ntiles * splits), dim3(NTHR), 0, stream, g, (const bf16*)x,
-                       (const bf16*)dy, g.Co, dw_packed, mps, ntiles, tiles_col);
+                       (const bf16*)dy, ldy_, dw_packed, mps, ntiles, tiles_col);
   } else if (dtype == VC_BF16) {
     const int64_t total = (int64_t)g.Co * g.K;
     hipLaunchKernelGGL((wgrad_naive_kernel<bf16>), dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, stream, g,
-                       (const bf16*)x, (const bf16*)dy, g.Co, dw_packed);
+                       (const bf16*)x, (const bf16*)dy, ldy_, dw_packed);
   } else if (dtype == VC_F32) {
     const int64_t total = (int64_t)g.Co * g.K;
     hipLaunchKernelGGL((wgrad_naive_kernel<float>), dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, stream, g,
-                       (const float*)x, (const float*)dy, g.Co, dw_packed);
+                       (const float*)x, (const float*)dy, ldy_, dw_packed);
   } else {
     vc_set_error("vc_conv_wgrad: unsupported dtype %d", dtype);
     return VC_ERR_DTYPE;

@@ -1,0 +1,527 @@
+// Bandwidth-bound kernels around the contractions (gfx950): clip layout conversion, pooling,
+// small elementwise ops, the LSTM cell, the fused cross-entropy head and the fused optimizer.
+// Channels-last everywhere; 8 channels (16 B of bf16 / 32 B of fp32) per lane per access.
+#include "vc_common.h"
+
+namespace {
+
+constexpr int NTHR = 256;
+
+inline int ew_grid(int64_t n) {
+  int64_t b = ceil_div64(n, NTHR);
+  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+// ---------------------------------------------------------------------------
+// Clip layout: fp32 [B][T][C][S] (frames NCHW, S = H*W)  ->  T [F][S][Cp], zero-padded
+// channels.  time_major: output frame f = t*B + b (BatchNorm groups contiguous);
+// otherwise f = b*T + t (Conv3D: [B][C][T][S] -> [B][T][S][Cp] uses chan_outer = 1).
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void clip_to_cl_kernel(const float* __restrict__ x, T* __restrict__ out, int B, int Tn, int C, int S,
+                                  int Cp, int time_major, int chan_outer) {
+  const int64_t total = (int64_t)B * Tn * S;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int s = (int)(idx % S);
+    const int f = (int)(idx / S);
+    int b, t;
+    if (time_major) {
+      t = f / B;
+      b = f - t * B;
+    } else {
+      b = f / Tn;
+      t = f - b * Tn;
+    }
+    T* o = out + idx * Cp;
+    for (int c = 0; c < Cp; ++c) {
+      float v = 0.f;
+      if (c < C) {
+        const size_t src = chan_outer ? (((size_t)b * C + c) * Tn + t) * S + s : (((size_t)b * Tn + t) * C + c) * S + s;
+        v = x[src];
+      }
+      o[c] = from_f32<T>(v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Max pooling over (H, W) of [N][H][W][C]; records the winning tap per output element.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ idx, int N,
+                                   int H, int W, int C8, int Ho, int Wo, int k, int s, int p) {
+  const int64_t total = (int64_t)N * Ho * Wo * C8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % C8);
+    int64_t t = i / C8;
+    const int ow = (int)(t % Wo);
+    t /= Wo;
+    const int oh = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    float best[8];
+    int bi[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      best[j] = -INFINITY;
+      bi[j] = 0;
+    }
+    for (int r = 0; r < k; ++r) {
+      const int ih = oh * s - p + r;
+      if ((unsigned)ih >= (unsigned)H) continue;
+      for (int q = 0; q < k; ++q) {
+        const int iw = ow * s - p + q;
+        if ((unsigned)iw >= (unsigned)W) continue;
+        const F8 v = load8(x + ((((size_t)n * H + ih) * W + iw) * C8 + cc) * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (v.v[j] > best[j]) {
+            best[j] = v.v[j];
+            bi[j] = r * k + q;
+          }
+      }
+    }
+    F8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.v[j] = best[j];
+    store8(y + i * 8, o);
+    if (idx) {
+      uint32_t lo = 0, hi = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        lo |= (uint32_t)bi[j] << (8 * j);
+        hi |= (uint32_t)bi[4 + j] << (8 * j);
+      }
+      *reinterpret_cast<uint2*>(idx + i * 8) = make_uint2(lo, hi);
+    }
+  }
+}
+
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx, T* __restrict__ dx, int N,
+                                   int H, int W, int C8, int Ho, int Wo, int k, int s, int p) {
+  const int64_t total = (int64_t)N * H * W * C8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % C8);
+    int64_t t = i / C8;
+    const int iw = (int)(t % W);
+    t /= W;
+    const int ih = (int)(t % H);
+    const int n = (int)(t / H);
+    F8 acc;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc.v[j] = 0.f;
+    // output windows that contain (ih, iw): oh*s - p <= ih <= oh*s - p + k - 1
+    const int oh_lo = max(0, (ih + p - k + s) / s), oh_hi = min(Ho - 1, (ih + p) / s);
+    const int ow_lo = max(0, (iw + p - k + s) / s), ow_hi = min(Wo - 1, (iw + p) / s);
+    for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+      const int r = ih - (oh * s - p);
+      if (r < 0 || r >= k) continue;
+      for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+        const int q = iw - (ow * s - p);
+        if (q < 0 || q >= k) continue;
+        const size_t o = ((((size_t)n * Ho + oh) * Wo + ow) * C8 + cc) * 8;
+        const uint2 w = *reinterpret_cast<const uint2*>(idx + o);
+        const F8 d = load8(dy + o);
+        const int tap = r * k + q;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int b = (int)(((j < 4 ? w.x : w.y) >> (8 * (j & 3))) & 0xff);
+          if (b == tap) acc.v[j] += d.v[j];
+        }
+      }
+    }
+    store8(dx + i * 8, acc);
+  }
+}
+
+// global average pool over S positions: [N][S][C] -> [N][C]
+template <typename T>
+__global__ void avgpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int S, int C8) {
+  const int64_t total = (int64_t)N * C8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % C8);
+    const int n = (int)(i / C8);
+    F8 acc;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc.v[j] = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const F8 v = load8(x + (((size_t)n * S + s) * C8 + cc) * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc.v[j] += v.v[j];
+    }
+    const float inv = 1.f / S;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc.v[j] *= inv;
+    store8(y + i * 8, acc);
+  }
+}
+
+template <typename T>
+__global__ void avgpool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int S, int C8) {
+  const int64_t total = (int64_t)N * S * C8;
+  const float inv = 1.f / S;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % C8);
+    const int n = (int)(i / ((int64_t)S * C8));
+    F8 d = load8(dy + ((size_t)n * C8 + cc) * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d.v[j] *= inv;
+    store8(dx + i * 8, d);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Small elementwise ops on [n8 * 8] elements.
+// OP 0: out = a + b              OP 1: out = a * (b > 0)   (ReLU backward: a = dout, b = act)
+// OP 2: out = relu(a)            OP 3: out = gelu(a)        OP 4: out = a * gelu'(b)
+// OP 5: out = sigmoid(a)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
+
+template <typename T, int OP>
+__global__ void ew_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, int64_t n8) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    F8 av = load8(a + i * 8), bv;
+    if (OP == 0 || OP == 1 || OP == 4) bv = load8(b + i * 8);
+    F8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (OP == 0) o.v[j] = av.v[j] + bv.v[j];
+      if (OP == 1) o.v[j] = bv.v[j] > 0.f ? av.v[j] : 0.f;
+      if (OP == 2) o.v[j] = fmaxf(av.v[j], 0.f);
+      if (OP == 3) o.v[j] = gelu_f(av.v[j]);
+      if (OP == 4) o.v[j] = av.v[j] * gelu_grad_f(bv.v[j]);
+      if (OP == 5) o.v[j] = sigmoid_f(av.v[j]);
+    }
+    store8(out + i * 8, o);
+  }
+}
+
+// dtype conversion: fp32 <-> T
+template <typename TI, typename TO>
+__global__ void cast_kernel(const TI* __restrict__ a, TO* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = from_f32<TO>(to_f32(a[i]));
+}
+
+// column sums of [M][C] (bias gradients): out[c] (+)= sum_m a[m][c]
+template <typename T>
+__global__ void colsum_kernel(const T* __restrict__ a, float* __restrict__ out, int M, int C, int lda,
+                              int rows_per_block) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  float acc = 0.f;
+  for (int r = r0; r < r1; ++r) acc += to_f32(a[(size_t)r * lda + c]);
+  atomicAdd(out + c, acc);
+}
+
+// ---------------------------------------------------------------------------
+// LSTM cell (PyTorch gate order i, f, g, o).  gates_x already holds x W_ih^T + b_ih + b_hh;
+// gates_h (nullable at the first step: zero state) holds h_{t-1} W_hh^T.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void lstm_cell_fwd_kernel(const float* __restrict__ gates_x, int ldx, const float* __restrict__ gates_h,
+                                     const float* __restrict__ c_prev, T* __restrict__ h_out, int ldh,
+                                     float* __restrict__ c_out, float* __restrict__ act_out, int B, int H) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * H) return;
+  const int b = i / H, j = i - b * H;
+  float pre[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    pre[k] = gates_x[(size_t)b * ldx + k * H + j];
+    if (gates_h) pre[k] += gates_h[(size_t)b * 4 * H + k * H + j];
+  }
+  const float ig = sigmoid_f(pre[0]), fg = sigmoid_f(pre[1]), gg = tanhf(pre[2]), og = sigmoid_f(pre[3]);
+  const float cp = c_prev ? c_prev[i] : 0.f;
+  const float c = fg * cp + ig * gg;
+  const float h = og * tanhf(c);
+  c_out[i] = c;
+  h_out[(size_t)b * ldh + j] = from_f32<T>(h);
+  float* a = act_out + (size_t)b * 4 * H + j;
+  a[0] = ig;
+  a[H] = fg;
+  a[2 * H] = gg;
+  a[3 * H] = og;
+}
+
+// dh = dh_out (gradient from the layer above / output at this step, nullable) + dh_rec (from step t+1, nullable)
+template <typename T>
+__global__ void lstm_cell_bwd_kernel(const T* __restrict__ dh_out, int ldo, const float* __restrict__ dh_rec,
+                                     const float* __restrict__ dc_next, const float* __restrict__ act,
+                                     const float* __restrict__ c, const float* __restrict__ c_prev,
+                                     T* __restrict__ dgates, float* __restrict__ dc_prev, int B, int H) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * H) return;
+  const int b = i / H, j = i - b * H;
+  float dh = 0.f;
+  if (dh_out) dh += to_f32(dh_out[(size_t)b * ldo + j]);
+  if (dh_rec) dh += dh_rec[i];
+  const float* a = act + (size_t)b * 4 * H + j;
+  const float ig = a[0], fg = a[H], gg = a[2 * H], og = a[3 * H];
+  const float tc = tanhf(c[i]);
+  float dc = dh * og * (1.f - tc * tc);
+  if (dc_next) dc += dc_next[i];
+  const float cp = c_prev ? c_prev[i] : 0.f;
+  const float d_o = dh * tc, d_i = dc * gg, d_g = dc * ig, d_f = dc * cp;
+  dc_prev[i] = dc * fg;
+  T* dg = dgates + (size_t)b * 4 * H + j;
+  dg[0] = from_f32<T>(d_i * ig * (1.f - ig));
+  dg[H] = from_f32<T>(d_f * fg * (1.f - fg));
+  dg[2 * H] = from_f32<T>(d_g * (1.f - gg * gg));
+  dg[3 * H] = from_f32<T>(d_o * og * (1.f - og));
+}
+
+// ---------------------------------------------------------------------------
+// Cross-entropy head: one wave per row of fp32 logits [B][ld]; mean loss, argmax,
+// number of correct predictions and dlogits = (softmax - onehot) * grad_scale.
+// ---------------------------------------------------------------------------
+template <typename TG>
+__global__ void ce_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ target,
+                          float* __restrict__ loss, int64_t* __restrict__ pred, int* __restrict__ correct,
+                          TG* __restrict__ dlogits, int ldd, int B, int C, float loss_scale, float grad_scale) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= B) return;
+  const float* lr = logits + (size_t)row * ld;
+  float mx = -INFINITY;
+  int mi = 0x7fffffff;
+  for (int c = lane; c < C; c += 64) {
+    const float v = lr[c];
+    if (v > mx) {
+      mx = v;
+      mi = c;
+    }
+  }
+  // wave arg-max with lowest index among equal maxima (torch.argmax on CPU returns the first)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(mx, o, 64);
+    const int oi = __shfl_xor(mi, o, 64);
+    if (ov > mx || (ov == mx && oi < mi)) {
+      mx = ov;
+      mi = oi;
+    }
+  }
+  float se = 0.f;
+  for (int c = lane; c < C; c += 64) se += __expf(lr[c] - mx);
+  se = wave_sum(se);
+  const float lse = mx + logf(se);
+  const int tgt = (int)target[row];
+  if (lane == 0) {
+    atomicAdd(loss, (lse - lr[tgt]) * loss_scale);
+    if (pred) pred[row] = mi;
+    if (correct && mi == tgt) atomicAdd(correct, 1);
+  }
+  if (dlogits) {
+    for (int c = lane; c < ldd; c += 64) {
+      float g = 0.f;
+      if (c < C) g = (__expf(lr[c] - lse) - (c == tgt ? 1.f : 0.f)) * grad_scale;
+      dlogits[(size_t)row * ldd + c] = from_f32<TG>(g);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Fused optimizer over one flat fp32 parameter buffer.
+// mode 0: Adam with L2 weight decay folded into the gradient (torch.optim.Adam)
+// mode 1: AdamW (decoupled decay)      mode 2: SGD with momentum (torch.optim.SGD, dampening 0)
+// ---------------------------------------------------------------------------
+__global__ void optim_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, int64_t n, int mode, float lr, float b1, float b2, float eps,
+                             float wd, float bc1, float bc2_sqrt, float grad_scale, int first_step) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float pv = p[i];
+    float gv = g[i] * grad_scale;
+    if (mode == 2) {
+      gv = fmaf(wd, pv, gv);
+      const float buf = first_step ? gv : fmaf(b1, m[i], gv);
+      m[i] = buf;
+      p[i] = pv - lr * buf;
+      continue;
+    }
+    if (mode == 0) gv = fmaf(wd, pv, gv);
+    else pv *= (1.f - lr * wd);
+    const float mv = b1 * m[i] + (1.f - b1) * gv;
+    const float vv = b2 * v[i] + (1.f - b2) * gv * gv;
+    m[i] = mv;
+    v[i] = vv;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    p[i] = pv - (lr / bc1) * (mv / denom);
+  }
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, who, ...)                              \
+  if (dtype == VC_BF16) { typedef bf16 T; __VA_ARGS__ }          \
+  else if (dtype == VC_F32) { typedef float T; __VA_ARGS__ }     \
+  else { vc_set_error("%s: unsupported dtype %d", who, dtype); return VC_ERR_DTYPE; }
+
+extern "C" {
+
+int vc_clip_to_channels_last(int dtype, const float* x, void* out, int B, int T_, int C, int S, int Cp, int time_major,
+                             int chan_outer, hipStream_t stream) {
+  VC_CHECK_ARG(x && out, "vc_clip_to_channels_last: null pointer");
+  VC_CHECK_SHAPE(B > 0 && T_ > 0 && C > 0 && S > 0 && Cp >= C, "vc_clip_to_channels_last: bad shape");
+  const int64_t total = (int64_t)B * T_ * S;
+  DISPATCH_T(dtype, "vc_clip_to_channels_last",
+             hipLaunchKernelGGL((clip_to_cl_kernel<T>), dim3(ew_grid(total)), dim3(NTHR), 0, stream, x, (T*)out, B, T_,
+                                C, S, Cp, time_major, chan_outer);)
+  VC_LAUNCH_CHECK("vc_clip_to_channels_last");
+  return VC_OK;
+}
+
+int vc_maxpool2d_fwd(int dtype, const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, int k, int s, int p,
+                     hipStream_t stream) {
+  VC_CHECK_ARG(x && y, "vc_maxpool2d_fwd: null pointer");
+  VC_CHECK_SHAPE(C % 8 == 0 && k > 0 && k * k <= 255 && s > 0 && p >= 0 && p < k, "vc_maxpool2d_fwd: bad shape");
+  const int Ho = (H + 2 * p - k) / s + 1, Wo = (W + 2 * p - k) / s + 1;
+  const int64_t total = (int64_t)N * Ho * Wo * (C / 8);
+  DISPATCH_T(dtype, "vc_maxpool2d_fwd",
+             hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(ew_grid(total)), dim3(NTHR), 0, stream, (const T*)x,
+                                (T*)y, idx, N, H, W, C / 8, Ho, Wo, k, s, p);)
+  VC_LAUNCH_CHECK("vc_maxpool2d_fwd");
+  return VC_OK;
+}
+
+int vc_maxpool2d_bwd(int dtype, const void* dy, const uint8_t* idx, void* dx, int N, int H, int W, int C, int k, int s,
+                     int p, hipStream_t stream) {
+  VC_CHECK_ARG(dy && idx && dx, "vc_maxpool2d_bwd: null pointer");
+  VC_CHECK_SHAPE(C % 8 == 0 && k > 0 && s > 0 && p >= 0 && p < k, "vc_maxpool2d_bwd: bad shape");
+  const int Ho = (H + 2 * p - k) / s + 1, Wo = (W + 2 * p - k) / s + 1;
+  const int64_t total = (int64_t)N * H * W * (C / 8);
+  DISPATCH_T(dtype, "vc_maxpool2d_bwd",
+             hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(ew_grid(total)), dim3(NTHR), 0, stream, (const T*)dy, idx,
+                                (T*)dx, N, H, W, C / 8, Ho, Wo, k, s, p);)
+  VC_LAUNCH_CHECK("vc_maxpool2d_bwd");
+  return VC_OK;
+}
+
+int vc_avgpool_fwd(int dtype, const void* x, void* y, int N, int S, int C, hipStream_t stream) {
+  VC_CHECK_ARG(x && y, "vc_avgpool_fwd: null pointer");
+  VC_CHECK_SHAPE(C % 8 == 0 && N > 0 && S > 0, "vc_avgpool_fwd: bad shape");
+  DISPATCH_T(dtype, "vc_avgpool_fwd",
+             hipLaunchKernelGGL((avgpool_fwd_kernel<T>), dim3(ew_grid((int64_t)N * (C / 8))), dim3(NTHR), 0, stream,
+                                (const T*)x, (T*)y, N, S, C / 8);)
+  VC_LAUNCH_CHECK("vc_avgpool_fwd");
+  return VC_OK;
+}
+
+int vc_avgpool_bwd(int dtype, const void* dy, void* dx, int N, int S, int C, hipStream_t stream) {
+  VC_CHECK_ARG(dy && dx, "vc_avgpool_bwd: null pointer");
+  VC_CHECK_SHAPE(C % 8 == 0 && N > 0 && S > 0, "vc_avgpool_bwd: bad shape");
+  DISPATCH_T(dtype, "vc_avgpool_bwd",
+             hipLaunchKernelGGL((avgpool_bwd_kernel<T>), dim3(ew_grid((int64_t)N * S * (C / 8))), dim3(NTHR), 0,
+                                stream, (const T*)dy, (T*)dx, N, S, C / 8);)
+  VC_LAUNCH_CHECK("vc_avgpool_bwd");
+  return VC_OK;
+}
+
+int vc_elementwise(int dtype, int op, const void* a, const void* b, void* out, int64_t n, hipStream_t stream) {
+  VC_CHECK_ARG(a && out, "vc_elementwise: null pointer");
+  VC_CHECK_SHAPE(n % 8 == 0 && n > 0, "vc_elementwise: element count must be a positive multiple of 8");
+  VC_CHECK_ARG(op >= 0 && op <= 5, "vc_elementwise: unknown op %d", op);
+  VC_CHECK_ARG(!(op == 0 || op == 1 || op == 4) || b, "vc_elementwise: op %d needs two inputs", op);
+  const int64_t n8 = n / 8;
+#define EW_CASE(OPN) \
+  case OPN:          \
+    hipLaunchKernelGGL((ew_kernel<T, OPN>), dim3(ew_grid(n8)), dim3(NTHR), 0, stream, (const T*)a, (const T*)b, (T*)out, n8); \
+    break;
+  DISPATCH_T(dtype, "vc_elementwise", switch (op) { EW_CASE(0) EW_CASE(1) EW_CASE(2) EW_CASE(3) EW_CASE(4) EW_CASE(5) })
+#undef EW_CASE
+  VC_LAUNCH_CHECK("vc_elementwise");
+  return VC_OK;
+}
+
+int vc_cast(int src_dtype, int dst_dtype, const void* a, void* out, int64_t n, hipStream_t stream) {
+  VC_CHECK_ARG(a && out && n > 0, "vc_cast: bad argument");
+  dim3 grid(ew_grid(n)), blk(NTHR);
+  if (src_dtype == VC_F32 && dst_dtype == VC_BF16)
+    hipLaunchKernelGGL((cast_kernel<float, bf16>), grid, blk, 0, stream, (const float*)a, (bf16*)out, n);
+  else if (src_dtype == VC_BF16 && dst_dtype == VC_F32)
+    hipLaunchKernelGGL((cast_kernel<bf16, float>), grid, blk, 0, stream, (const bf16*)a, (float*)out, n);
+  else if (src_dtype == VC_F32 && dst_dtype == VC_F32)
+    hipLaunchKernelGGL((cast_kernel<float, float>), grid, blk, 0, stream, (const float*)a, (float*)out, n);
+  else if (src_dtype == VC_BF16 && dst_dtype == VC_BF16)
+    hipLaunchKernelGGL((cast_kernel<bf16, bf16>), grid, blk, 0, stream, (const bf16*)a, (bf16*)out, n);
+  else { vc_set_error("vc_cast: unsupported dtypes %d -> %d", src_dtype, dst_dtype); return VC_ERR_DTYPE; }
+  VC_LAUNCH_CHECK("vc_cast");
+  return VC_OK;
+}
+
+// out[c] += sum over rows (caller zeroes or keeps a running gradient)
+int vc_colsum(int dtype, const void* a, float* out, int M, int C, int lda, hipStream_t stream) {
+  VC_CHECK_ARG(a && out && M > 0 && C > 0 && lda >= C, "vc_colsum: bad argument");
+  int rows_per_block = 64;
+  while (ceil_div(M, rows_per_block) > 512) rows_per_block *= 2;
+  dim3 grid(ceil_div(C, 64), ceil_div(M, rows_per_block));
+  DISPATCH_T(dtype, "vc_colsum",
+             hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(64), 0, stream, (const T*)a, out, M, C, lda,
+                                rows_per_block);)
+  VC_LAUNCH_CHECK("vc_colsum");
+  return VC_OK;
+}
+
+int vc_lstm_cell_fwd(int dtype, const float* gates_x, int ldx, const float* gates_h, const float* c_prev, void* h_out,
+                     int ldh, float* c_out, float* act_out, int B, int H, hipStream_t stream) {
+  VC_CHECK_ARG(gates_x && h_out && c_out && act_out, "vc_lstm_cell_fwd: null pointer");
+  DISPATCH_T(dtype, "vc_lstm_cell_fwd",
+             hipLaunchKernelGGL((lstm_cell_fwd_kernel<T>), dim3(ceil_div(B * H, NTHR)), dim3(NTHR), 0, stream,
+                                gates_x, ldx, gates_h, c_prev, (T*)h_out, ldh, c_out, act_out, B, H);)
+  VC_LAUNCH_CHECK("vc_lstm_cell_fwd");
+  return VC_OK;
+}
+
+int vc_lstm_cell_bwd(int dtype, const void* dh_out, int ldo, const float* dh_rec, const float* dc_next,
+                     const float* act, const float* c, const float* c_prev, void* dgates, float* dc_prev, int B, int H,
+                     hipStream_t stream) {
+  VC_CHECK_ARG(act && c && dgates && dc_prev, "vc_lstm_cell_bwd: null pointer");
+  DISPATCH_T(dtype, "vc_lstm_cell_bwd",
+             hipLaunchKernelGGL((lstm_cell_bwd_kernel<T>), dim3(ceil_div(B * H, NTHR)), dim3(NTHR), 0, stream,
+                                (const T*)dh_out, ldo, dh_rec, dc_next, act, c, c_prev, (T*)dgates, dc_prev, B, H);)
+  VC_LAUNCH_CHECK("vc_lstm_cell_bwd");
+  return VC_OK;
+}
+
+// loss[0] and correct[0] are accumulated into (caller zeroes them); dlogits has `ldd` columns,
+// the ones beyond C are written as zero.
+int vc_ce_fwd_bwd(int grad_dtype, const float* logits, int ld, const int64_t* target, float* loss, int64_t* pred,
+                  int* correct, void* dlogits, int ldd, int B, int C, float loss_scale, float grad_scale,
+                  hipStream_t stream) {
+  VC_CHECK_ARG(logits && target && loss, "vc_ce_fwd_bwd: null pointer");
+  VC_CHECK_SHAPE(B > 0 && C > 0 && ld >= C && (!dlogits || ldd >= C), "vc_ce_fwd_bwd: bad shape");
+  dim3 grid(ceil_div(B, 4)), blk(256);
+  if (grad_dtype == VC_BF16)
+    hipLaunchKernelGGL((ce_kernel<bf16>), grid, blk, 0, stream, logits, ld, target, loss, pred, correct,
+                       (bf16*)dlogits, ldd, B, C, loss_scale, grad_scale);
+  else if (grad_dtype == VC_F32)
+    hipLaunchKernelGGL((ce_kernel<float>), grid, blk, 0, stream, logits, ld, target, loss, pred, correct,
+                       (float*)dlogits, ldd, B, C, loss_scale, grad_scale);
+  else { vc_set_error("vc_ce_fwd_bwd: unsupported dtype %d", grad_dtype); return VC_ERR_DTYPE; }
+  VC_LAUNCH_CHECK("vc_ce_fwd_bwd");
+  return VC_OK;
+}
+
+int vc_optim_step(int mode, float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
+                  float eps, float wd, int step, float grad_scale, hipStream_t stream) {
+  VC_CHECK_ARG(p && g && m && n > 0 && step >= 1, "vc_optim_step: bad argument");
+  VC_CHECK_ARG(mode == 2 || v, "vc_optim_step: second-moment buffer missing");
+  VC_CHECK_ARG(mode >= 0 && mode <= 2, "vc_optim_step: unknown mode %d", mode);
+  const double bc1 = 1.0 - pow((double)b1, (double)step);
+  const double bc2 = 1.0 - pow((double)b2, (double)step);
+  hipLaunchKernelGGL(optim_kernel, dim3(ew_grid(n)), dim3(NTHR), 0, stream, p, g, m, v, n, mode, lr, b1, b2, eps, wd,
+                     (float)bc1, (float)sqrt(bc2), grad_scale, step == 1);
+  VC_LAUNCH_CHECK("vc_optim_step");
+  return VC_OK;
+}
+
+}  // extern "C"

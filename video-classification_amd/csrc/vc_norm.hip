@@ -1,0 +1,477 @@
+// BatchNorm (training mode, statistics per GROUP of rows) and LayerNorm for channels-last
+// activations [M][C] on gfx950.  All kernels are HBM-bound: 16-byte (8 x bf16) or 32-byte
+// (8 x fp32) accesses per lane, fp32 arithmetic.
+//
+// Grouping: the reference runs its frame encoders once per time step, so BatchNorm
+// statistics are taken over the B frames of ONE time step and the running statistics get T
+// momentum updates per forward, in time order.  Frames are laid out time-major here
+// (frame = t*B + b), so a group is a contiguous block of `rpg` rows and G = T.
+// Conv3D / plain batches use G = 1.
+#include "vc_common.h"
+
+namespace {
+
+constexpr int NTHR = 256;
+
+// per-(group, channel) sums of v1 and v2 over the rows of a group
+// MODE 0: v1 = y,  v2 = y*y                       (forward statistics)
+// MODE 1: v1 = dz, v2 = dz * xhat                 (backward reductions), dz = dout * (act > 0 if relu)
+template <typename T, int MODE>
+__global__ void bn_reduce_kernel(const T* __restrict__ y, const T* __restrict__ dout, const T* __restrict__ act,
+                                 const float* __restrict__ mean, const float* __restrict__ invstd,
+                                 float* __restrict__ s1, float* __restrict__ s2, int C, int rpg, int rows_per_block,
+                                 int relu) {
+  __shared__ float red[2][NTHR][8];
+  const int C8 = C >> 3;
+  const int lanesC = C8 < NTHR ? C8 : NTHR;
+  const int RL = NTHR / lanesC;
+  const int tid = threadIdx.x;
+  const int cl = tid % lanesC, rl = tid / lanesC;
+  const int g = blockIdx.y;
+  const int r_begin = blockIdx.x * rows_per_block;
+  const int r_end = min(rpg, r_begin + rows_per_block);
+  for (int cc0 = 0; cc0 < C8; cc0 += lanesC) {  // trip count is uniform over the block (barriers inside)
+    const int cc = cc0 + cl;
+    const bool cvalid = cc < C8;
+    float a1[8], a2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a1[i] = a2[i] = 0.f;
+    if (rl < RL && cvalid) {
+      float mu[8], is[8];
+      if (MODE == 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          mu[i] = mean[g * C + cc * 8 + i];
+          is[i] = invstd[g * C + cc * 8 + i];
+        }
+      }
+      for (int r = r_begin + rl; r < r_end; r += RL) {
+        const size_t off = ((size_t)g * rpg + r) * C + cc * 8;
+        const F8 yv = load8(y + off);
+        if (MODE == 0) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            a1[i] += yv.v[i];
+            a2[i] = fmaf(yv.v[i], yv.v[i], a2[i]);
+          }
+        } else {
+          F8 dv = load8(dout + off);
+          if (relu) {
+            const F8 av = load8(act + off);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dv.v[i] = av.v[i] > 0.f ? dv.v[i] : 0.f;
+          }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            a1[i] += dv.v[i];
+            a2[i] = fmaf(dv.v[i], (yv.v[i] - mu[i]) * is[i], a2[i]);
+          }
+        }
+      }
+    }
+    // reduce over the row lanes through LDS
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      red[0][tid][i] = a1[i];
+      red[1][tid][i] = a2[i];
+    }
+    __syncthreads();
+    if (rl == 0 && cvalid) {
+      for (int k = 1; k < RL; ++k) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          a1[i] += red[0][k * lanesC + cl][i];
+          a2[i] += red[1][k * lanesC + cl][i];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        atomicAdd(s1 + g * C + cc * 8 + i, a1[i]);
+        atomicAdd(s2 + g * C + cc * 8 + i, a2[i]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ sum, const float* __restrict__ sumsq,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                   float* __restrict__ scale, float* __restrict__ shift, int G, int C, float cnt,
+                                   float eps, float momentum, int update_running) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float rm = 0.f, rv = 0.f;
+  if (update_running) {
+    rm = running_mean[c];
+    rv = running_var[c];
+  }
+  const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+  for (int g = 0; g < G; ++g) {
+    const double m = (double)sum[g * C + c] / cnt;
+    double var = (double)sumsq[g * C + c] / cnt - m * m;
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    mean_out[g * C + c] = (float)m;
+    invstd_out[g * C + c] = is;
+    const float sc = ga * is;
+    scale[g * C + c] = sc;
+    shift[g * C + c] = be - (float)m * sc;
+    if (update_running) {
+      rm = (1.f - momentum) * rm + momentum * (float)m;
+      rv = (1.f - momentum) * rv + momentum * (float)(var * (cnt / (cnt - 1.0)));
+    }
+  }
+  if (update_running) {
+    running_mean[c] = rm;
+    running_var[c] = rv;
+  }
+}
+
+// scale/shift from running statistics (eval mode), G = 1
+__global__ void bn_eval_params_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                      float* __restrict__ scale, float* __restrict__ shift, int C, float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float sc = (gamma ? gamma[c] : 1.f) * rsqrtf(running_var[c] + eps);
+  scale[c] = sc;
+  shift[c] = (beta ? beta[c] : 0.f) - running_mean[c] * sc;
+}
+
+// out = act(y * scale[g] + shift[g] (+ residual))
+template <typename T>
+__global__ void bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                const float* __restrict__ shift, const T* __restrict__ residual, T* __restrict__ out,
+                                int64_t n8, int C8, int rpg, int relu) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n8; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = idx / C8;
+    const int cc = (int)(idx - m * C8);
+    const int g = (int)(m / rpg);
+    const F8 yv = load8(y + idx * 8);
+    const F8 sc = load8(scale + (size_t)g * C8 * 8 + cc * 8);
+    const F8 sh = load8(shift + (size_t)g * C8 * 8 + cc * 8);
+    F8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o.v[i] = fmaf(yv.v[i], sc.v[i], sh.v[i]);
+    if (residual) {
+      const F8 rv = load8(residual + idx * 8);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o.v[i] += rv.v[i];
+    }
+    if (relu) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o.v[i] = fmaxf(o.v[i], 0.f);
+    }
+    store8(out + idx * 8, o);
+  }
+}
+
+// dy = scale * (dz - s1/cnt - xhat * s2/cnt); optionally dres = dz
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ y, const T* __restrict__ dout, const T* __restrict__ act,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const float* __restrict__ scale, const float* __restrict__ s1,
+                                    const float* __restrict__ s2, T* __restrict__ dy, T* __restrict__ dres, int64_t n8,
+                                    int C8, int rpg, float inv_cnt, int relu) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n8; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = idx / C8;
+    const int cc = (int)(idx - m * C8);
+    const int g = (int)(m / rpg);
+    const size_t po = (size_t)g * C8 * 8 + cc * 8;
+    const F8 yv = load8(y + idx * 8);
+    F8 dv = load8(dout + idx * 8);
+    if (relu) {
+      const F8 av = load8(act + idx * 8);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dv.v[i] = av.v[i] > 0.f ? dv.v[i] : 0.f;
+    }
+    if (dres) store8(dres + idx * 8, dv);
+    const F8 mu = load8(mean + po), is = load8(invstd + po), sc = load8(scale + po), a1 = load8(s1 + po),
+             a2 = load8(s2 + po);
+    F8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float xh = (yv.v[i] - mu.v[i]) * is.v[i];
+      o.v[i] = sc.v[i] * (dv.v[i] - a1.v[i] * inv_cnt - xh * a2.v[i] * inv_cnt);
+    }
+    store8(dy + idx * 8, o);
+  }
+}
+
+// dgamma[c] (+)= sum_g s2[g][c]; dbeta[c] (+)= sum_g s1[g][c]
+__global__ void bn_bwd_params_kernel(const float* __restrict__ s1, const float* __restrict__ s2,
+                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int G, int C,
+                                     int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f, b = 0.f;
+  for (int g = 0; g < G; ++g) {
+    a += s2[g * C + c];
+    b += s1[g * C + c];
+  }
+  if (dgamma) dgamma[c] = accumulate ? dgamma[c] + a : a;
+  if (dbeta) dbeta[c] = accumulate ? dbeta[c] + b : b;
+}
+
+// ------------------------------ LayerNorm ---------------------------------
+// one wave per row; C % 8 == 0; saves mean and rstd per row
+template <typename T>
+__global__ void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                              T* __restrict__ out, float* __restrict__ mean, float* __restrict__ rstd, int M, int C,
+                              float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int C8 = C >> 3;
+  const T* xr = x + (size_t)row * C;
+  float s = 0.f;
+  for (int cc = lane; cc < C8; cc += 64) {
+    const F8 v = load8(xr + cc * 8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += v.v[i];
+  }
+  const float mu = wave_sum(s) / C;
+  float q = 0.f;
+  for (int cc = lane; cc < C8; cc += 64) {
+    const F8 v = load8(xr + cc * 8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q = fmaf(v.v[i] - mu, v.v[i] - mu, q);
+  }
+  const float rs = rsqrtf(wave_sum(q) / C + eps);
+  if (lane == 0) {
+    mean[row] = mu;
+    rstd[row] = rs;
+  }
+  for (int cc = lane; cc < C8; cc += 64) {
+    const F8 v = load8(xr + cc * 8), ga = load8(gamma + cc * 8), be = load8(beta + cc * 8);
+    F8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o.v[i] = fmaf((v.v[i] - mu) * rs, ga.v[i], be.v[i]);
+    store8(out + (size_t)row * C + cc * 8, o);
+  }
+}
+
+// dx per row; dgamma/dbeta partial sums accumulated with atomics per block
+template <typename T>
+__global__ void ln_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dout, const float* __restrict__ gamma,
+                              const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dx,
+                              float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int C,
+                              int rows_per_block) {
+  extern __shared__ float lds[];  // [2][C]
+  const int C8 = C >> 3;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) lds[i] = 0.f;
+  __syncthreads();
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(M, r0 + rows_per_block);
+  // per-lane partial dgamma/dbeta live in registers for the channels this lane owns
+  // (C <= 64*8*4 = 2048 supported per lane with 4 chunks)
+  float pg[4][8], pb[4][8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pg[k][i] = pb[k][i] = 0.f;
+  for (int row = r0 + wave; row < r1; row += nw) {
+    const T* xr = x + (size_t)row * C;
+    const T* dr = dout + (size_t)row * C;
+    const float mu = mean[row], rs = rstd[row];
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int cc = lane + 64 * k;
+      if (cc < C8) {
+        const F8 v = load8(xr + cc * 8), d = load8(dr + cc * 8), ga = load8(gamma + cc * 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float xh = (v.v[i] - mu) * rs, dg = d.v[i] * ga.v[i];
+          a += dg;
+          b = fmaf(dg, xh, b);
+          pg[k][i] = fmaf(d.v[i], xh, pg[k][i]);
+          pb[k][i] += d.v[i];
+        }
+      }
+    }
+    a = wave_sum(a) / C;
+    b = wave_sum(b) / C;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int cc = lane + 64 * k;
+      if (cc < C8) {
+        const F8 v = load8(xr + cc * 8), d = load8(dr + cc * 8), ga = load8(gamma + cc * 8);
+        F8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float xh = (v.v[i] - mu) * rs;
+          o.v[i] = rs * (d.v[i] * ga.v[i] - a - xh * b);
+        }
+        store8(dx + (size_t)row * C + cc * 8, o);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int cc = lane + 64 * k;
+    if (cc < C8) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        atomicAdd(&lds[cc * 8 + i], pg[k][i]);
+        atomicAdd(&lds[C + cc * 8 + i], pb[k][i]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += blockDim.x) {
+    atomicAdd(dgamma + i, lds[i]);
+    atomicAdd(dbeta + i, lds[C + i]);
+  }
+}
+
+template <typename T, int MODE>
+int launch_reduce(const void* y, const void* dout, const void* act, const float* mean, const float* invstd, float* s1,
+                  float* s2, int G, int rpg, int C, int relu, hipStream_t stream) {
+  int rows_per_block = 256;
+  // enough blocks to fill the chip, few enough that the atomics stay cheap
+  while (rows_per_block < rpg && (int64_t)ceil_div(rpg, rows_per_block) * G > 2048) rows_per_block *= 2;
+  dim3 grid(ceil_div(rpg, rows_per_block), G);
+  hipLaunchKernelGGL((bn_reduce_kernel<T, MODE>), grid, dim3(NTHR), 0, stream, (const T*)y, (const T*)dout,
+                     (const T*)act, mean, invstd, s1, s2, C, rpg, rows_per_block, relu);
+  return VC_OK;
+}
+
+inline int ew_grid(int64_t n) {
+  int64_t b = ceil_div64(n, NTHR);
+  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" {
+
+// s1/s2 [G][C] must be zeroed by the caller (they are accumulated with atomics)
+int vc_bn_stats(int dtype, const void* y, float* sum, float* sumsq, int G, int rpg, int C, hipStream_t stream) {
+  VC_CHECK_ARG(y && sum && sumsq, "vc_bn_stats: null pointer");
+  VC_CHECK_SHAPE(C % 8 == 0 && G > 0 && rpg > 0, "vc_bn_stats: need C %% 8 == 0 (C=%d)", C);
+  if (dtype == VC_BF16) launch_reduce<bf16, 0>(y, nullptr, nullptr, nullptr, nullptr, sum, sumsq, G, rpg, C, 0, stream);
+  else if (dtype == VC_F32) launch_reduce<float, 0>(y, nullptr, nullptr, nullptr, nullptr, sum, sumsq, G, rpg, C, 0, stream);
+  else { vc_set_error("vc_bn_stats: unsupported dtype %d", dtype); return VC_ERR_DTYPE; }
+  VC_LAUNCH_CHECK("vc_bn_stats");
+  return VC_OK;
+}
+
+int vc_bn_finalize(const float* sum, const float* sumsq, const float* gamma, const float* beta, float* running_mean,
+                   float* running_var, float* mean, float* invstd, float* scale, float* shift, int G, int C, int rpg,
+                   float eps, float momentum, int update_running, hipStream_t stream) {
+  VC_CHECK_ARG(sum && sumsq && mean && invstd && scale && shift, "vc_bn_finalize: null pointer");
+  VC_CHECK_ARG(!update_running || (running_mean && running_var), "vc_bn_finalize: running stats missing");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, stream, sum, sumsq, gamma, beta,
+                     running_mean, running_var, mean, invstd, scale, shift, G, C, (float)rpg, eps, momentum,
+                     update_running);
+  VC_LAUNCH_CHECK("vc_bn_finalize");
+  return VC_OK;
+}
+
+int vc_bn_eval_params(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                      float* scale, float* shift, int C, float eps, hipStream_t stream) {
+  VC_CHECK_ARG(running_mean && running_var && scale && shift, "vc_bn_eval_params: null pointer");
+  hipLaunchKernelGGL(bn_eval_params_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, stream, gamma, beta, running_mean,
+                     running_var, scale, shift, C, eps);
+  VC_LAUNCH_CHECK("vc_bn_eval_params");
+  return VC_OK;
+}
+
+int vc_bn_apply(int dtype, const void* y, const float* scale, const float* shift, const void* residual, void* out,
+                int G, int rpg, int C, int relu, hipStream_t stream) {
+  VC_CHECK_ARG(y && scale && shift && out, "vc_bn_apply: null pointer");
+  VC_CHECK_SHAPE(C % 8 == 0, "vc_bn_apply: need C %% 8 == 0 (C=%d)", C);
+  const int64_t n8 = (int64_t)G * rpg * (C / 8);
+  if (dtype == VC_BF16)
+    hipLaunchKernelGGL((bn_apply_kernel<bf16>), dim3(ew_grid(n8)), dim3(NTHR), 0, stream, (const bf16*)y, scale, shift,
+                       (const bf16*)residual, (bf16*)out, n8, C / 8, rpg, relu);
+  else if (dtype == VC_F32)
+    hipLaunchKernelGGL((bn_apply_kernel<float>), dim3(ew_grid(n8)), dim3(NTHR), 0, stream, (const float*)y, scale,
+                       shift, (const float*)residual, (float*)out, n8, C / 8, rpg, relu);
+  else { vc_set_error("vc_bn_apply: unsupported dtype %d", dtype); return VC_ERR_DTYPE; }
+  VC_LAUNCH_CHECK("vc_bn_apply");
+  return VC_OK;
+}
+
+// s1/s2 [G][C] must be zeroed by the caller
+int vc_bn_bwd_reduce(int dtype, const void* y, const void* dout, const void* act, const float* mean,
+                     const float* invstd, float* s1, float* s2, int G, int rpg, int C, int relu, hipStream_t stream) {
+  VC_CHECK_ARG(y && dout && mean && invstd && s1 && s2 && (!relu || act), "vc_bn_bwd_reduce: null pointer");
+  VC_CHECK_SHAPE(C % 8 == 0, "vc_bn_bwd_reduce: need C %% 8 == 0 (C=%d)", C);
+  if (dtype == VC_BF16) launch_reduce<bf16, 1>(y, dout, act, mean, invstd, s1, s2, G, rpg, C, relu, stream);
+  else if (dtype == VC_F32) launch_reduce<float, 1>(y, dout, act, mean, invstd, s1, s2, G, rpg, C, relu, stream);
+  else { vc_set_error("vc_bn_bwd_reduce: unsupported dtype %d", dtype); return VC_ERR_DTYPE; }
+  VC_LAUNCH_CHECK("vc_bn_bwd_reduce");
+  return VC_OK;
+}
+
+int vc_bn_bwd_apply(int dtype, const void* y, const void* dout, const void* act, const float* mean,
+                    const float* invstd, const float* scale, const float* s1, const float* s2, void* dy, void* dres,
+                    int G, int rpg, int C, int relu, hipStream_t stream) {
+  VC_CHECK_ARG(y && dout && mean && invstd && scale && s1 && s2 && dy && (!relu || act), "vc_bn_bwd_apply: null pointer");
+  VC_CHECK_SHAPE(C % 8 == 0, "vc_bn_bwd_apply: need C %% 8 == 0 (C=%d)", C);
+  const int64_t n8 = (int64_t)G * rpg * (C / 8);
+  const float inv_cnt = 1.f / (float)rpg;
+  if (dtype == VC_BF16)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16>), dim3(ew_grid(n8)), dim3(NTHR), 0, stream, (const bf16*)y,
+                       (const bf16*)dout, (const bf16*)act, mean, invstd, scale, s1, s2, (bf16*)dy, (bf16*)dres, n8,
+                       C / 8, rpg, inv_cnt, relu);
+  else if (dtype == VC_F32)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(ew_grid(n8)), dim3(NTHR), 0, stream, (const float*)y,
+                       (const float*)dout, (const float*)act, mean, invstd, scale, s1, s2, (float*)dy, (float*)dres,
+                       n8, C / 8, rpg, inv_cnt, relu);
+  else { vc_set_error("vc_bn_bwd_apply: unsupported dtype %d", dtype); return VC_ERR_DTYPE; }
+  VC_LAUNCH_CHECK("vc_bn_bwd_apply");
+  return VC_OK;
+}
+
+int vc_bn_bwd_params(const float* s1, const float* s2, float* dgamma, float* dbeta, int G, int C, int accumulate,
+                     hipStream_t stream) {
+  VC_CHECK_ARG(s1 && s2, "vc_bn_bwd_params: null pointer");
+  hipLaunchKernelGGL(bn_bwd_params_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, stream, s1, s2, dgamma, dbeta, G, C,
+                     accumulate);
+  VC_LAUNCH_CHECK("vc_bn_bwd_params");
+  return VC_OK;
+}
+
+int vc_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* out, float* mean,
+                     float* rstd, int M, int C, float eps, hipStream_t stream) {
+  VC_CHECK_ARG(x && gamma && beta && out && mean && rstd, "vc_layernorm_fwd: null pointer");
+  VC_CHECK_SHAPE(C % 8 == 0 && M > 0, "vc_layernorm_fwd: need C %% 8 == 0 (C=%d)", C);
+  dim3 grid(ceil_div(M, 4));
+  if (dtype == VC_BF16)
+    hipLaunchKernelGGL((ln_fwd_kernel<bf16>), grid, dim3(256), 0, stream, (const bf16*)x, gamma, beta, (bf16*)out,
+                       mean, rstd, M, C, eps);
+  else if (dtype == VC_F32)
+    hipLaunchKernelGGL((ln_fwd_kernel<float>), grid, dim3(256), 0, stream, (const float*)x, gamma, beta, (float*)out,
+                       mean, rstd, M, C, eps);
+  else { vc_set_error("vc_layernorm_fwd: unsupported dtype %d", dtype); return VC_ERR_DTYPE; }
+  VC_LAUNCH_CHECK("vc_layernorm_fwd");
+  return VC_OK;
+}
+
+// dgamma/dbeta are accumulated into (caller zeroes or keeps running gradient)
+int vc_layernorm_bwd(int dtype, const void* x, const void* dout, const float* gamma, const float* mean,
+                     const float* rstd, void* dx, float* dgamma, float* dbeta, int M, int C, hipStream_t stream) {
+  VC_CHECK_ARG(x && dout && gamma && mean && rstd && dx && dgamma && dbeta, "vc_layernorm_bwd: null pointer");
+  VC_CHECK_SHAPE(C % 8 == 0 && C <= 2048 && M > 0, "vc_layernorm_bwd: need C %% 8 == 0 and C <= 2048 (C=%d)", C);
+  int rows_per_block = 64;
+  while (ceil_div(M, rows_per_block) > 1024) rows_per_block *= 2;
+  dim3 grid(ceil_div(M, rows_per_block));
+  const size_t lds = 2 * (size_t)C * sizeof(float);
+  if (dtype == VC_BF16)
+    hipLaunchKernelGGL((ln_bwd_kernel<bf16>), grid, dim3(256), lds, stream, (const bf16*)x, (const bf16*)dout, gamma,
+                       mean, rstd, (bf16*)dx, dgamma, dbeta, M, C, rows_per_block);
+  else if (dtype == VC_F32)
+    hipLaunchKernelGGL((ln_bwd_kernel<float>), grid, dim3(256), lds, stream, (const float*)x, (const float*)dout,
+                       gamma, mean, rstd, (float*)dx, dgamma, dbeta, M, C, rows_per_block);
+  else { vc_set_error("vc_layernorm_bwd: unsupported dtype %d", dtype); return VC_ERR_DTYPE; }
+  VC_LAUNCH_CHECK("vc_layernorm_bwd");
+  return VC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,733 @@
+"""Autograd-aware wrappers over the C ABI of libvc_hip (hand-written gfx950 kernels).
+
+Activations are channels-last ("CL") tensors in the compute dtype (bfloat16 by default, float32 for
+the exact path): ``[N, D, H, W, C]`` for convolutions, ``[M, C]`` for linear layers, with C a multiple
+of 8.  PyTorch only owns the memory and the autograd graph; every arithmetic step below is a call
+into libvc_hip.  Parameter gradients are accumulated by the kernels directly into ``param.grad``
+(fp32), so the autograd functions return ``None`` for parameter inputs.
+"""
+import torch
+
+from . import _lib as L
+
+# bumped whenever parameters are rewritten behind autograd's back (fused optimizer, load_state_dict)
+_weights_epoch = 0
+
+
+def bump_weights_epoch():
+    global _weights_epoch
+    _weights_epoch += 1
+
+
+# When set to a list, every contraction launch appends (tag, algorithmic_flops, start_event, end_event),
+# with the events recorded on the launch stream around the kernel (bench.py's roofline measurement).
+PROFILE = None
+
+
+def _timed(tag, flops, launch):
+    if PROFILE is None:
+        launch()
+        return
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    launch()
+    e.record()
+    PROFILE.append((tag, flops, s, e))
+
+
+def _require_cuda(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: libvc_hip kernels need tensors on the MI355X (got device {t.device}); "
+                           "there is no CPU fallback")
+
+
+def pad8(c):
+    return (c + 7) // 8 * 8
+
+
+def _grad_buf(p):
+    """fp32 gradient buffer of a parameter (created zeroed on first use)."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+    return p.grad
+
+
+_grad_ready_hook = None
+
+
+def set_grad_ready_hook(fn):
+    """fn(param) is called right after the kernels that produce param's gradient have been enqueued
+    (the data-parallel trainer uses it to start a bucket's all-reduce while backward continues)."""
+    global _grad_ready_hook
+    _grad_ready_hook = fn
+
+
+def _ready(*params):
+    if _grad_ready_hook is not None:
+        for p in params:
+            if p is not None and p.requires_grad:
+                _grad_ready_hook(p)
+
+
+def cast(t, dtype):
+    """dtype conversion with the library's cast kernel (float32 <-> bfloat16)."""
+    if t.dtype == dtype:
+        return t
+    t = t.contiguous()
+    out = torch.empty_like(t, dtype=dtype)
+    L.call("vc_cast", L.dtype_code(t.dtype), L.dtype_code(dtype), L.ptr(t), L.ptr(out), L.i64(t.numel()), L.stream())
+    return out
+
+
+class _Cast(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, dtype):
+        ctx.src = t.dtype
+        return cast(t, dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return cast(g, ctx.src), None
+
+
+def cast_ag(t, dtype):
+    return t if t.dtype == dtype else _Cast.apply(t, dtype)
+
+
+def elementwise(op, a, b=None):
+    a = a.contiguous()
+    out = torch.empty_like(a)
+    L.call("vc_elementwise", L.dtype_code(a.dtype), op, L.ptr(a), L.ptr(b.contiguous() if b is not None else None),
+           L.ptr(out), L.i64(a.numel()), L.stream())
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# clip layout
+# ----------------------------------------------------------------------------------------------
+def clip_to_frames(x, dtype, cpad=8):
+    """fp32 clip [B,T,C,H,W] -> channels-last frames [T*B, 1, H, W, cpad], time-major (frame = t*B + b)."""
+    _require_cuda(x, "clip_to_frames")
+    B, T, C, H, W = x.shape
+    x = x.contiguous().float()
+    out = torch.empty(T * B, 1, H, W, cpad, device=x.device, dtype=dtype)
+    L.call("vc_clip_to_channels_last", L.dtype_code(dtype), L.ptr(x), L.ptr(out), B, T, C, H * W, cpad, 1, 0,
+           L.stream())
+    return out
+
+
+def volume_to_cl(x, dtype, cpad=8):
+    """fp32 volume [B,C,T,H,W] -> channels-last [B, T, H, W, cpad]."""
+    _require_cuda(x, "volume_to_cl")
+    B, C, T, H, W = x.shape
+    x = x.contiguous().float()
+    out = torch.empty(B, T, H, W, cpad, device=x.device, dtype=dtype)
+    L.call("vc_clip_to_channels_last", L.dtype_code(dtype), L.ptr(x), L.ptr(out), B, T, C, H * W, cpad, 0, 1,
+           L.stream())
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# convolution / linear
+# ----------------------------------------------------------------------------------------------
+def _triple(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v, v)
+
+
+def _packed_weights(weight, ci, taps, cip, cop, dtype):
+    """(forward pack [cop][taps][cip], transposed pack [Ci][taps][cop]) in the compute dtype."""
+    # The pack is cached on the parameter object itself (it dies with it) and is valid while neither
+    # autograd's version counter nor the library's own "weights rewritten" epoch has moved.
+    key = (weight.data_ptr(), weight._version, _weights_epoch, dtype, cip, cop, taps)
+    cache = getattr(weight, "_vc_pack", None)
+    if cache is not None and cache[0] == key:
+        return cache[1], cache[2]
+    co = weight.shape[0]
+    wf = torch.zeros(cop, taps, cip, device=weight.device, dtype=dtype)
+    wt = torch.empty(ci, taps, cop, device=weight.device, dtype=dtype)
+    w = weight.detach().contiguous()
+    L.call("vc_pack_weight", L.dtype_code(dtype), L.ptr(w), L.ptr(wf), L.ptr(wt), co, ci, taps, cip, cop, L.stream())
+    weight._vc_pack = (key, wf, wt)
+    return wf, wt
+
+
+class _Conv(torch.autograd.Function):
+    """y = conv(x, weight) + bias (optionally ReLU) on channels-last tensors."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, kernel, stride, padding, relu, out_f32, ci):
+        _require_cuda(x, "conv")
+        x = x.contiguous()
+        dtype = x.dtype
+        N, D, H, W, cip = x.shape
+        co = weight.shape[0]
+        ci = ci or weight.shape[1]
+        if cip < ci or cip % 8:
+            raise RuntimeError(f"conv: input has {cip} channels, weight expects {ci} (padded to a multiple of 8)")
+        k, s, p = _triple(kernel), _triple(stride), _triple(padding)
+        taps = k[0] * k[1] * k[2]
+        cop = pad8(co)
+        Do, Ho, Wo = [(i + 2 * pp - kk) // ss + 1 for i, kk, ss, pp in zip((D, H, W), k, s, p)]
+        desc = [N, D, H, W, cip, Do, Ho, Wo, cop, *k, *s, *p]
+        if weight.numel() != co * ci * taps:
+            raise RuntimeError(f"conv: weight of shape {tuple(weight.shape)} is not [Co={co}, Ci={ci}, taps={taps}]")
+        wf, wt = _packed_weights(weight, ci, taps, cip, cop, dtype)
+        b = None
+        if bias is not None:
+            b = bias.detach()
+            if cop != co:
+                b = torch.cat([b, b.new_zeros(cop - co)])
+        f32 = bool(out_f32) or dtype == torch.float32
+        y = torch.empty(N, Do, Ho, Wo, cop, device=x.device, dtype=torch.float32 if f32 else dtype)
+        flops = 2.0 * N * Do * Ho * Wo * co * ci * taps  # algorithmic: true channel counts, no padding
+        _timed("conv_fwd", flops, lambda: L.call(
+            "vc_conv_fwd", L.int_array(desc), L.dtype_code(dtype), L.ptr(x), 0, L.ptr(wf), L.ptr(b), L.ptr(y), 0,
+            int(relu), int(f32), 0, L.stream()))
+        ctx.flops = flops
+        ctx.desc, ctx.taps, ctx.relu, ctx.has_bias = desc, taps, relu, bias is not None
+        ctx.dims = (co, ci, cip, cop)
+        ctx.weight, ctx.bias = weight, bias
+        ctx.save_for_backward(x, wt, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wt, y = ctx.saved_tensors
+        co, ci, cip, cop = ctx.dims
+        dtype = x.dtype
+        code = L.dtype_code(dtype)
+        dy = cast(dy.contiguous(), dtype)
+        if ctx.relu:
+            dy = elementwise(1, dy, cast(y, dtype))
+        desc = L.int_array(ctx.desc)
+        weight, bias = ctx.weight, ctx.bias
+        if weight.requires_grad:
+            dwp = torch.zeros(cop, ctx.taps, cip, device=x.device, dtype=torch.float32)
+            _timed("conv_wgrad", ctx.flops, lambda: L.call(
+                "vc_conv_wgrad", desc, code, L.ptr(x), 0, L.ptr(dy), 0, L.ptr(dwp), 0, L.stream()))
+            L.call("vc_unpack_wgrad", L.ptr(dwp), L.ptr(_grad_buf(weight)), co, ci, ctx.taps, cip, 1, L.stream())
+        if bias is not None and bias.requires_grad:
+            M = dy.numel() // cop
+            L.call("vc_colsum", code, L.ptr(dy), L.ptr(_grad_buf(bias)), M, co, cop, L.stream())
+        _ready(weight, bias)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if cip != ci:
+                raise RuntimeError("conv: data gradient requested for a channel-padded input")
+            dx = torch.empty_like(x)
+            _timed("conv_dgrad", ctx.flops, lambda: L.call(
+                "vc_conv_dgrad", desc, code, L.ptr(dy), 0, L.ptr(wt), L.ptr(dx), 0, int(dtype == torch.float32), 0,
+                L.stream()))
+        return dx, None, None, None, None, None, None, None, None
+
+
+def conv(x, weight, bias=None, kernel=1, stride=1, padding=0, relu=False, out_f32=False, ci=None):
+    """x: [N,D,H,W,C] channels-last.  weight: fp32 parameter whose memory is [Co][Ci][taps] (a Conv2d/Conv3d
+    weight, or a Linear weight [Co, Ci*taps] read as a convolution over the whole feature map when `ci` is given)."""
+    return _Conv.apply(x, weight, bias, kernel, stride, padding, relu, out_f32, ci)
+
+
+def linear(x, weight, bias=None, relu=False, out_f32=False):
+    """x: [M, C] -> [M, pad8(Co)]."""
+    M, C = x.shape
+    y = conv(x.view(M, 1, 1, 1, C), weight, bias, 1, 1, 0, relu, out_f32)
+    return y.view(M, y.shape[-1])
+
+
+# ----------------------------------------------------------------------------------------------
+# BatchNorm with per-group (per time step) statistics
+# ----------------------------------------------------------------------------------------------
+class _BatchNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, groups, momentum, eps, relu, residual, training):
+        _require_cuda(y, "batch_norm")
+        y = y.contiguous()
+        C = y.shape[-1]
+        M = y.numel() // C
+        code = L.dtype_code(y.dtype)
+        dev = y.device
+        ga = gamma.detach() if gamma is not None else None
+        be = beta.detach() if beta is not None else None
+        if training:
+            G = groups
+            if M % G:
+                raise RuntimeError(f"batch_norm: {M} rows do not split into {G} groups")
+            rpg = M // G
+            sums = torch.zeros(2, G, C, device=dev, dtype=torch.float32)
+            stat = torch.empty(4, G, C, device=dev, dtype=torch.float32)  # mean, invstd, scale, shift
+            L.call("vc_bn_stats", code, L.ptr(y), L.ptr(sums[0]), L.ptr(sums[1]), G, rpg, C, L.stream())
+            upd = running_mean is not None
+            L.call("vc_bn_finalize", L.ptr(sums[0]), L.ptr(sums[1]), L.ptr(ga), L.ptr(be), L.ptr(running_mean),
+                   L.ptr(running_var), L.ptr(stat[0]), L.ptr(stat[1]), L.ptr(stat[2]), L.ptr(stat[3]), G, C, rpg,
+                   float(eps), float(momentum), int(upd), L.stream())
+        else:
+            G, rpg = 1, M
+            stat = torch.empty(4, 1, C, device=dev, dtype=torch.float32)
+            L.call("vc_bn_eval_params", L.ptr(ga), L.ptr(be), L.ptr(running_mean), L.ptr(running_var), L.ptr(stat[2]),
+                   L.ptr(stat[3]), C, float(eps), L.stream())
+        out = torch.empty_like(y)
+        res = residual.contiguous() if residual is not None else None
+        L.call("vc_bn_apply", code, L.ptr(y), L.ptr(stat[2]), L.ptr(stat[3]), L.ptr(res), L.ptr(out), G, rpg, C,
+               int(relu), L.stream())
+        ctx.G, ctx.rpg, ctx.C, ctx.relu, ctx.training = G, rpg, C, relu, training
+        ctx.has_res = residual is not None
+        ctx.gamma, ctx.beta = gamma, beta
+        ctx.save_for_backward(y, out if relu else None, stat)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if not ctx.training:
+            raise RuntimeError("batch_norm: backward through eval-mode BatchNorm is not implemented")
+        y, out, stat = ctx.saved_tensors
+        G, rpg, C = ctx.G, ctx.rpg, ctx.C
+        code = L.dtype_code(y.dtype)
+        dout = cast(dout.contiguous(), y.dtype)
+        s = torch.zeros(2, G, C, device=y.device, dtype=torch.float32)
+        L.call("vc_bn_bwd_reduce", code, L.ptr(y), L.ptr(dout), L.ptr(out), L.ptr(stat[0]), L.ptr(stat[1]), L.ptr(s[0]),
+               L.ptr(s[1]), G, rpg, C, int(ctx.relu), L.stream())
+        dy = torch.empty_like(y)
+        dres = torch.empty_like(y) if ctx.has_res else None
+        L.call("vc_bn_bwd_apply", code, L.ptr(y), L.ptr(dout), L.ptr(out), L.ptr(stat[0]), L.ptr(stat[1]),
+               L.ptr(stat[2]), L.ptr(s[0]), L.ptr(s[1]), L.ptr(dy), L.ptr(dres), G, rpg, C, int(ctx.relu), L.stream())
+        dg = _grad_buf(ctx.gamma) if ctx.gamma is not None and ctx.gamma.requires_grad else None
+        db = _grad_buf(ctx.beta) if ctx.beta is not None and ctx.beta.requires_grad else None
+        if dg is not None or db is not None:
+            L.call("vc_bn_bwd_params", L.ptr(s[0]), L.ptr(s[1]), L.ptr(dg), L.ptr(db), G, C, 1, L.stream())
+        _ready(ctx.gamma, ctx.beta)
+        return dy, None, None, None, None, None, None, None, None, dres, None
+
+
+def batch_norm(y, bn, groups, relu=False, residual=None):
+    """bn: an nn.BatchNorm{1,2,3}d module holding the parameters/buffers (its own forward is not used)."""
+    training = bn.training or bn.running_mean is None
+    out = _BatchNorm.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, groups,
+                           bn.momentum if bn.momentum is not None else 0.1, bn.eps, relu, residual, training)
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += groups
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# pooling
+# ----------------------------------------------------------------------------------------------
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k, s, p):
+        x = x.contiguous()
+        N, H, W, C = x.shape
+        Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        y = torch.empty(N, Ho, Wo, C, device=x.device, dtype=x.dtype)
+        idx = torch.empty(N, Ho, Wo, C, device=x.device, dtype=torch.uint8)
+        L.call("vc_maxpool2d_fwd", L.dtype_code(x.dtype), L.ptr(x), L.ptr(y), L.ptr(idx), N, H, W, C, k, s, p,
+               L.stream())
+        ctx.geom = (N, H, W, C, k, s, p)
+        ctx.save_for_backward(idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        N, H, W, C, k, s, p = ctx.geom
+        dy = dy.contiguous()
+        dx = torch.empty(N, H, W, C, device=dy.device, dtype=dy.dtype)
+        L.call("vc_maxpool2d_bwd", L.dtype_code(dy.dtype), L.ptr(dy), L.ptr(idx), L.ptr(dx), N, H, W, C, k, s, p,
+               L.stream())
+        return dx, None, None, None
+
+
+def max_pool2d(x, k, s, p=0):
+    """x: [N,H,W,C] channels-last."""
+    return _MaxPool.apply(x, k, s, p)
+
+
+class _AvgPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        N, S, C = x.shape
+        y = torch.empty(N, C, device=x.device, dtype=x.dtype)
+        L.call("vc_avgpool_fwd", L.dtype_code(x.dtype), L.ptr(x), L.ptr(y), N, S, C, L.stream())
+        ctx.geom = (N, S, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, S, C = ctx.geom
+        dy = dy.contiguous()
+        dx = torch.empty(N, S, C, device=dy.device, dtype=dy.dtype)
+        L.call("vc_avgpool_bwd", L.dtype_code(dy.dtype), L.ptr(dy), L.ptr(dx), N, S, C, L.stream())
+        return dx
+
+
+def global_avg_pool(x):
+    """x: [N,S,C] -> [N,C] (mean over S)."""
+    return _AvgPool.apply(x)
+
+
+class _Relu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = elementwise(2, x)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return elementwise(1, cast(dy.contiguous(), y.dtype), y)
+
+
+def relu(x):
+    return _Relu.apply(x)
+
+
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return elementwise(0, a, b)
+
+    @staticmethod
+    def backward(ctx, d):
+        return d, d
+
+
+def add(a, b):
+    return _Add.apply(a, b)
+
+
+# ----------------------------------------------------------------------------------------------
+# LSTM (multi-layer, optionally bidirectional), time-major
+# ----------------------------------------------------------------------------------------------
+def _lin_desc(M, K, N):
+    return L.int_array([M, 1, 1, 1, K, 1, 1, 1, N, 1, 1, 1, 1, 1, 1, 0, 0, 0])
+
+
+def _off(t, elems):
+    """pointer to element offset `elems` inside tensor t"""
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr() + elems * t.element_size())
+
+
+class _LSTM(torch.autograd.Function):
+    """x [T,B,In] -> out [T,B,H*dirs]; zero initial state (DecoderRNN passes None; TCG_LSTM uses the default).
+
+    Per layer and direction: one MFMA GEMM hoists x W_ih^T + b for all T, then per step one small GEMM
+    h_{t-1} W_hh^T and the fused cell kernel.  Backward is explicit BPTT with the same kernels; the weight
+    gradients of all steps are one GEMM over the whole sequence."""
+
+    @staticmethod
+    def forward(ctx, x, H, layers, bidir, *params):
+        _require_cuda(x, "lstm")
+        x = x.contiguous()
+        T, B, In = x.shape
+        dt = x.dtype
+        code = L.dtype_code(dt)
+        dirs = 2 if bidir else 1
+        dev = x.device
+        f32 = torch.float32
+        saved = []
+        inp = x
+        st = L.stream()
+        for l in range(layers):
+            Kin = inp.shape[-1]
+            out = torch.empty(T, B, H * dirs, device=dev, dtype=dt)
+            for d in range(dirs):
+                w_ih, w_hh, b_ih, b_hh = params[(l * dirs + d) * 4:(l * dirs + d) * 4 + 4]
+                wih_f, wih_t = _packed_weights(w_ih, Kin, 1, Kin, 4 * H, dt)
+                whh_f, whh_t = _packed_weights(w_hh, H, 1, H, 4 * H, dt)
+                bsum = elementwise(0, b_ih.detach(), b_hh.detach())
+                gx = torch.empty(T, B, 4 * H, device=dev, dtype=f32)
+                L.call("vc_conv_fwd", _lin_desc(T * B, Kin, 4 * H), code, L.ptr(inp), 0, L.ptr(wih_f), L.ptr(bsum),
+                       L.ptr(gx), 0, 0, 1, 0, st)
+                c = torch.empty(T, B, H, device=dev, dtype=f32)
+                act = torch.empty(T, B, 4 * H, device=dev, dtype=f32)
+                gh = torch.empty(B, 4 * H, device=dev, dtype=f32)
+                order = range(T) if d == 0 else range(T - 1, -1, -1)
+                prev = None
+                for t in order:
+                    if prev is not None:
+                        L.call("vc_conv_fwd", _lin_desc(B, H, 4 * H), code, _off(out, (prev * B) * H * dirs + d * H),
+                               H * dirs, L.ptr(whh_f), L.ptr(None), L.ptr(gh), 0, 0, 1, 0, st)
+                    L.call("vc_lstm_cell_fwd", code, _off(gx, t * B * 4 * H), 4 * H, L.ptr(gh if prev is not None else None),
+                           _off(c, prev * B * H) if prev is not None else L.ptr(None),
+                           _off(out, (t * B) * H * dirs + d * H), H * dirs, _off(c, t * B * H),
+                           _off(act, t * B * 4 * H), B, H, st)
+                    prev = t
+                saved.append((inp, c, act, wih_t, whh_t))
+            saved.append(out)
+            inp = out
+        ctx.meta = (T, B, In, H, layers, dirs)
+        ctx.params = params
+        ctx.saved_objs = saved
+        return inp
+
+    @staticmethod
+    def backward(ctx, dout):
+        T, B, In, H, layers, dirs = ctx.meta
+        params = ctx.params
+        saved = ctx.saved_objs
+        dev = dout.device
+        f32 = torch.float32
+        st = L.stream()
+        # unpack per-layer records: for each layer, `dirs` tuples then the layer output
+        recs = []
+        i = 0
+        for l in range(layers):
+            per_dir = [saved[i + d] for d in range(dirs)]
+            out = saved[i + dirs]
+            recs.append((per_dir, out))
+            i += dirs + 1
+        dt = recs[0][1].dtype
+        code = L.dtype_code(dt)
+        dlayer = cast(dout.contiguous(), dt)
+        for l in range(layers - 1, -1, -1):
+            per_dir, out = recs[l]
+            inp = per_dir[0][0]
+            Kin = inp.shape[-1]
+            need_dinp = l > 0 or ctx.needs_input_grad[0]
+            dinp = torch.empty(T, B, Kin, device=dev, dtype=dt) if need_dinp else None
+            for d in range(dirs):
+                _, c, act, wih_t, whh_t = per_dir[d]
+                w_ih, w_hh, b_ih, b_hh = params[(l * dirs + d) * 4:(l * dirs + d) * 4 + 4]
+                dg = torch.empty(T, B, 4 * H, device=dev, dtype=dt)
+                dh_rec = torch.empty(B, H, device=dev, dtype=f32)
+                dc = [torch.empty(B, H, device=dev, dtype=f32), torch.empty(B, H, device=dev, dtype=f32)]
+                order = list(range(T)) if d == 0 else list(range(T - 1, -1, -1))
+                nxt = None  # the step processed after t in forward order (whose gradients flow back into t)
+                for k in range(T - 1, -1, -1):
+                    t = order[k]
+                    prev = order[k - 1] if k > 0 else None
+                    if nxt is not None:
+                        L.call("vc_conv_dgrad", _lin_desc(B, H, 4 * H), code, _off(dg, nxt * B * 4 * H), 0,
+                               L.ptr(whh_t), L.ptr(dh_rec), 0, 1, 0, st)
+                    L.call("vc_lstm_cell_bwd", code, _off(dlayer, (t * B) * H * dirs + d * H), H * dirs,
+                           L.ptr(dh_rec if nxt is not None else None), L.ptr(dc[k & 1] if nxt is not None else None),
+                           _off(act, t * B * 4 * H), _off(c, t * B * H),
+                           _off(c, prev * B * H) if prev is not None else L.ptr(None), _off(dg, t * B * 4 * H),
+                           L.ptr(dc[(k & 1) ^ 1]), B, H, st)
+                    nxt = t
+                # weight gradients over the whole sequence
+                if w_ih.requires_grad:
+                    dwp = torch.zeros(4 * H, Kin, device=dev, dtype=f32)
+                    L.call("vc_conv_wgrad", _lin_desc(T * B, Kin, 4 * H), code, L.ptr(inp), 0, L.ptr(dg), 0,
+                           L.ptr(dwp), 0, st)
+                    L.call("vc_unpack_wgrad", L.ptr(dwp), L.ptr(_grad_buf(w_ih)), 4 * H, Kin, 1, Kin, 1, st)
+                if w_hh.requires_grad and T > 1:
+                    dwp = torch.zeros(4 * H, H, device=dev, dtype=f32)
+                    # pairs (h_prev, dgates_t): forward dir h[0..T-2] with dg[1..T-1]; reverse dir h[1..T-1] with dg[0..T-2]
+                    h_off = 0 if d == 0 else 1
+                    g_off = 1 if d == 0 else 0
+                    L.call("vc_conv_wgrad", _lin_desc((T - 1) * B, H, 4 * H), code,
+                           _off(out, (h_off * B) * H * dirs + d * H), H * dirs, _off(dg, g_off * B * 4 * H), 0,
+                           L.ptr(dwp), 0, st)
+                    L.call("vc_unpack_wgrad", L.ptr(dwp), L.ptr(_grad_buf(w_hh)), 4 * H, H, 1, H, 1, st)
+                for b_ in (b_ih, b_hh):
+                    if b_.requires_grad:
+                        L.call("vc_colsum", code, L.ptr(dg), L.ptr(_grad_buf(b_)), T * B, 4 * H, 4 * H, st)
+                _ready(w_ih, w_hh, b_ih, b_hh)
+                if need_dinp:
+                    L.call("vc_conv_dgrad", _lin_desc(T * B, Kin, 4 * H), code, L.ptr(dg), 0, L.ptr(wih_t),
+                           L.ptr(dinp), 0, int(dt == torch.float32), int(d > 0), st)
+            dlayer = dinp
+        return (dlayer, None, None, None) + (None,) * len(params)
+
+
+def lstm(x_tm, lstm_module):
+    """x_tm: [T,B,In] in the compute dtype; lstm_module: nn.LSTM holding the parameters (inter-layer
+    dropout must be 0 or the module in eval mode)."""
+    m = lstm_module
+    if m.training and m.dropout > 0 and m.num_layers > 1:
+        raise RuntimeError("lstm: inter-layer dropout > 0 in training mode is not supported by the HIP path")
+    dirs = 2 if m.bidirectional else 1
+    params = []
+    for l in range(m.num_layers):
+        for d in range(dirs):
+            sfx = f"_l{l}" + ("_reverse" if d else "")
+            params += [getattr(m, "weight_ih" + sfx), getattr(m, "weight_hh" + sfx), getattr(m, "bias_ih" + sfx),
+                       getattr(m, "bias_hh" + sfx)]
+    return _LSTM.apply(x_tm, m.hidden_size, m.num_layers, m.bidirectional, *params)
+
+
+# ----------------------------------------------------------------------------------------------
+# cross-entropy head
+# ----------------------------------------------------------------------------------------------
+class _CrossEntropy(torch.autograd.Function):
+    """mean cross-entropy over the batch (nn.CrossEntropyLoss default), fused with its gradient, the
+    arg-max prediction and the number of correct predictions."""
+
+    @staticmethod
+    def forward(ctx, logits, target, num_classes, stats):
+        _require_cuda(logits, "cross_entropy")
+        if logits.dtype != torch.float32:
+            raise RuntimeError("cross_entropy: logits must be float32")
+        B = logits.shape[0]
+        ld = logits.stride(0)
+        tgt = target.reshape(-1).contiguous()
+        loss = torch.zeros(1, device=logits.device, dtype=torch.float32)
+        pred = torch.empty(B, device=logits.device, dtype=torch.int64)
+        correct = torch.zeros(1, device=logits.device, dtype=torch.int32)
+        dl = torch.empty(B, ld, device=logits.device, dtype=torch.float32)
+        L.call("vc_ce_fwd_bwd", L.VC_F32, L.ptr(logits), ld, L.ptr(tgt), L.ptr(loss), L.ptr(pred), L.ptr(correct),
+               L.ptr(dl), ld, B, num_classes, 1.0 / B, 1.0 / B, L.stream())
+        ctx.save_for_backward(dl)
+        ctx.C = logits.shape[1]
+        if stats is not None:
+            stats["pred"], stats["correct"] = pred, correct
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        # g is the 0-dim upstream gradient (1 for a plain loss.backward()); scaling [B, C] by it is plumbing
+        d = dl[:, :ctx.C]
+        return d * g, None, None, None
+
+
+def cross_entropy(logits, target, stats=None):
+    """logits [B,C] float32 (a view of a row-padded buffer is fine), target int64 [B] or [B,1]."""
+    return _CrossEntropy.apply(logits, target, logits.shape[1], stats)
+
+
+# ----------------------------------------------------------------------------------------------
+# dropout
+# ----------------------------------------------------------------------------------------------
+_dropout_seed = [0x5EED]
+
+
+def manual_seed(seed):
+    """Seed of the dropout generator (counter-based; every call advances it)."""
+    _dropout_seed[0] = int(seed) & 0x7FFFFFFFFFFFFFFF
+
+
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        import ctypes
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        mask = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+        _dropout_seed[0] = (_dropout_seed[0] * 6364136223846793005 + 1442695040888963407) & 0x7FFFFFFFFFFFFFFF
+        L.call("vc_dropout_fwd", L.dtype_code(x.dtype), L.ptr(x), L.ptr(out), L.ptr(mask), L.i64(x.numel()), float(p),
+               ctypes.c_uint64(_dropout_seed[0]), L.stream())
+        ctx.p = p
+        ctx.save_for_backward(mask)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        L.call("vc_dropout_bwd", L.dtype_code(dy.dtype), L.ptr(dy), L.ptr(mask), L.ptr(dx), L.i64(dy.numel()),
+               float(ctx.p), L.stream())
+        return dx, None
+
+
+def dropout(x, p, training):
+    if not training or p <= 0.0:
+        return x
+    return _Dropout.apply(x, p)
+
+
+# ----------------------------------------------------------------------------------------------
+# TCG-LSTM fusion
+# ----------------------------------------------------------------------------------------------
+class _TCGInputs(torch.autograd.Function):
+    """g [B,T,E], c [B,T,K,E] (fp32) -> short_in [T,B,2E] = [g | mean_K c], long_in [Tl,B,E] = g[:, ::down]."""
+
+    @staticmethod
+    def forward(ctx, g, c, down, dtype):
+        _require_cuda(g, "tcg_inputs")
+        g = g.contiguous().float()
+        c = c.contiguous().float()
+        B, T, E = g.shape
+        K = c.shape[2]
+        Tl = (T + down - 1) // down
+        s_in = torch.empty(T, B, 2 * E, device=g.device, dtype=dtype)
+        l_in = torch.empty(Tl, B, E, device=g.device, dtype=dtype)
+        L.call("vc_tcg_inputs", L.dtype_code(dtype), L.ptr(g), L.ptr(c), L.ptr(s_in), L.ptr(l_in), B, T, Tl, K, E, down,
+               L.stream())
+        ctx.meta = (B, T, Tl, K, E, down)
+        return s_in, l_in
+
+    @staticmethod
+    def backward(ctx, ds, dl):
+        B, T, Tl, K, E, down = ctx.meta
+        ds, dl = ds.contiguous(), dl.contiguous()
+        dg = torch.empty(B, T, E, device=ds.device, dtype=torch.float32)
+        dc = torch.empty(B, T, K, E, device=ds.device, dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        L.call("vc_tcg_inputs_bwd", L.dtype_code(ds.dtype), L.ptr(ds), L.ptr(dl), L.ptr(dg), L.ptr(dc), B, T, Tl, K, E,
+               down, L.stream())
+        return dg, dc, None, None
+
+
+def tcg_inputs(g, c, down, dtype):
+    return _TCGInputs.apply(g, c, down, dtype)
+
+
+class _TCGFuse(torch.autograd.Function):
+    """h_s [T,B,2H], h_l [Tl,B,H] -> clip feature [B,2H] (interpolate, sigmoid gate, blend, softmax-over-time pool).
+    The gate's Linear(4H -> 2H) runs on the MFMA GEMM; everything else is three fused kernels."""
+
+    @staticmethod
+    def forward(ctx, hs, hl, gate_w, gate_b):
+        hs, hl = hs.contiguous(), hl.contiguous()
+        T, B, F2 = hs.shape
+        H = F2 // 2
+        Tl = hl.shape[0]
+        dt = hs.dtype
+        code = L.dtype_code(dt)
+        dev = hs.device
+        st = L.stream()
+        cat = torch.empty(T, B, 4 * H, device=dev, dtype=dt)
+        L.call("vc_tcg_prep", code, L.ptr(hs), L.ptr(hl), L.ptr(cat), T, Tl, B, H, st)
+        wf, wt = _packed_weights(gate_w, 4 * H, 1, 4 * H, 2 * H, dt)
+        z = torch.empty(T, B, 2 * H, device=dev, dtype=torch.float32)
+        L.call("vc_conv_fwd", _lin_desc(T * B, 4 * H, 2 * H), code, L.ptr(cat), 0, L.ptr(wf), L.ptr(gate_b.detach()),
+               L.ptr(z), 0, 0, 1, 0, st)
+        gate = torch.empty(T, B, 2 * H, device=dev, dtype=torch.float32)
+        h = torch.empty(T, B, 2 * H, device=dev, dtype=torch.float32)
+        alpha = torch.empty(B, T, device=dev, dtype=torch.float32)
+        clip = torch.empty(B, 2 * H, device=dev, dtype=dt)
+        L.call("vc_tcg_fuse_fwd", code, L.ptr(z), L.ptr(cat), L.ptr(gate), L.ptr(h), L.ptr(alpha), L.ptr(clip), T, B, H,
+               st)
+        ctx.meta = (T, Tl, B, H)
+        ctx.gate_w, ctx.gate_b = gate_w, gate_b
+        ctx.save_for_backward(cat, gate, h, alpha, wt)
+        return clip
+
+    @staticmethod
+    def backward(ctx, dclip):
+        cat, gate, h, alpha, wt = ctx.saved_tensors
+        T, Tl, B, H = ctx.meta
+        dt = cat.dtype
+        code = L.dtype_code(dt)
+        dev = cat.device
+        st = L.stream()
+        dclip = cast(dclip.contiguous(), dt)
+        dz = torch.empty(T, B, 2 * H, device=dev, dtype=dt)
+        dhs = torch.empty(T, B, 2 * H, device=dev, dtype=torch.float32)
+        dup2 = torch.empty(T, B, 2 * H, device=dev, dtype=torch.float32)
+        L.call("vc_tcg_fuse_bwd", code, L.ptr(dclip), L.ptr(cat), L.ptr(gate), L.ptr(h), L.ptr(alpha), L.ptr(dz),
+               L.ptr(dhs), L.ptr(dup2), T, B, H, st)
+        desc = _lin_desc(T * B, 4 * H, 2 * H)
+        gw, gb = ctx.gate_w, ctx.gate_b
+        if gw.requires_grad:
+            dwp = torch.zeros(2 * H, 4 * H, device=dev, dtype=torch.float32)
+            L.call("vc_conv_wgrad", desc, code, L.ptr(cat), 0, L.ptr(dz), 0, L.ptr(dwp), 0, st)
+            L.call("vc_unpack_wgrad", L.ptr(dwp), L.ptr(_grad_buf(gw)), 2 * H, 4 * H, 1, 4 * H, 1, st)
+        if gb.requires_grad:
+            L.call("vc_colsum", code, L.ptr(dz), L.ptr(_grad_buf(gb)), T * B, 2 * H, 2 * H, st)
+        _ready(gw, gb)
+        dcat = torch.empty(T, B, 4 * H, device=dev, dtype=dt)
+        L.call("vc_conv_dgrad", desc, code, L.ptr(dz), 0, L.ptr(wt), L.ptr(dcat), 0, int(dt == torch.float32), 0, st)
+        dhs_out = torch.empty(T, B, 2 * H, device=dev, dtype=dt)
+        dhl = torch.empty(Tl, B, H, device=dev, dtype=dt)
+        L.call("vc_tcg_combine_bwd", code, L.ptr(dcat), L.ptr(dhs), L.ptr(dup2), L.ptr(dhs_out), L.ptr(dhl), T, Tl, B, H,
+               st)
+        return dhs_out, dhl, None, None
+
+
+def tcg_fuse(hs, hl, gate_linear):
+    return _TCGFuse.apply(hs, hl, gate_linear.weight, gate_linear.bias)

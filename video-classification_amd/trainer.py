@@ -1,0 +1,357 @@
+"""Training-step plumbing around the HIP modules: flat parameter / gradient buffers, the fused
+optimizer, bucketed data-parallel gradient all-reduce over RCCL, and drop-in ``train_epoch`` /
+``validate_epoch`` / ``get_optimizer`` / ``get_scheduler`` / checkpoint helpers with the reference's
+signatures (utils/common/training_utils.py:49-163, 199-243, 311-353).
+
+One process drives one GPU.  Replicas hold full weights; each rank works on its own clips; the only
+exchange step is the gradient all-reduce (the reference's ``nn.DataParallel``, train.py:515-518,
+is replaced by this).  BatchNorm statistics stay per replica and per time step, as under
+DataParallel.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+
+
+# --------------------------------------------------------------------------------------
+# flat buffers
+# --------------------------------------------------------------------------------------
+class FlatParams:
+    """Re-homes every parameter of `model` into one fp32 buffer (and its gradient into a second one) so
+    that the optimizer is one kernel launch and gradient buckets are plain slices.  Parameters keep
+    their identity, shape and state_dict keys; only their storage moves."""
+
+    ALIGN = 64  # elements: every parameter starts on a 256-byte boundary
+
+    def __init__(self, model):
+        params = [p for p in model.parameters() if p.requires_grad]
+        if not params:
+            raise ValueError("model has no trainable parameters")
+        dev = params[0].device
+        self.params = params
+        self.offsets = []
+        off = 0
+        for p in params:
+            if p.dtype != torch.float32:
+                raise TypeError("master parameters must be float32")
+            self.offsets.append(off)
+            off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.total = off
+        self.data = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(off, device=dev, dtype=torch.float32)
+        for p, o in zip(params, self.offsets):
+            n = p.numel()
+            self.data[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.data[o:o + n].view(p.shape)
+            p.grad = self.grad[o:o + n].view(p.shape)
+        ops.bump_weights_epoch()
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def view_of(self, buf, i):
+        o, p = self.offsets[i], self.params[i]
+        return buf[o:o + p.numel()].view(p.shape)
+
+
+# --------------------------------------------------------------------------------------
+# fused optimizer (torch.optim.Optimizer subclass so that torch LR schedulers and the reference's
+# checkpoint format keep working)
+# --------------------------------------------------------------------------------------
+class FusedOptimizer(torch.optim.Optimizer):
+    MODES = {"adam": 0, "adamw": 1, "sgd": 2}
+
+    def __init__(self, model_or_flat, name="adam", lr=1e-3, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8,
+                 momentum=0.9):
+        self.flat = model_or_flat if isinstance(model_or_flat, FlatParams) else FlatParams(model_or_flat)
+        name = name.lower()
+        if name not in self.MODES:
+            raise ValueError(f"Unsupported optimizer: {name}")
+        self.mode = self.MODES[name]
+        if name == "adamw" and weight_decay is None:
+            weight_decay = 1e-2
+        defaults = dict(lr=lr, weight_decay=weight_decay, betas=betas, eps=eps, momentum=momentum)
+        super().__init__(self.flat.params, defaults)
+        self.m = torch.zeros_like(self.flat.data)
+        self.v = torch.zeros_like(self.flat.data) if self.mode != 2 else None
+        self.steps = 0
+        self.grad_scale = 1.0
+        self.bucketer = None
+        for i, p in enumerate(self.flat.params):
+            st = self.state[p]
+            if self.mode == 2:
+                st["momentum_buffer"] = self.flat.view_of(self.m, i)
+            else:
+                st["step"] = torch.tensor(0.0)
+                st["exp_avg"] = self.flat.view_of(self.m, i)
+                st["exp_avg_sq"] = self.flat.view_of(self.v, i)
+
+    def zero_grad(self, set_to_none=False):
+        self.flat.zero_grad()
+        if self.bucketer is not None:
+            self.bucketer.reset()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if self.bucketer is not None:
+            self.bucketer.finish()
+        g = self.param_groups[0]
+        self.steps += 1
+        b1, b2 = g["betas"]
+        if self.mode == 2:
+            b1 = g["momentum"]
+        L.call("vc_optim_step", self.mode, L.ptr(self.flat.data), L.ptr(self.flat.grad), L.ptr(self.m), L.ptr(self.v),
+               L.i64(self.flat.total), float(g["lr"]), float(b1), float(b2), float(g["eps"]),
+               float(g["weight_decay"]), self.steps, float(self.grad_scale), L.stream())
+        if self.mode != 2:
+            for p in self.flat.params:
+                self.state[p]["step"] += 1
+        ops.bump_weights_epoch()
+
+    def load_state_dict(self, state_dict):
+        # torch re-creates the state tensors; copy them back into the flat buffers
+        super().load_state_dict(state_dict)
+        for i, p in enumerate(self.flat.params):
+            st = self.state[p]
+            if self.mode == 2:
+                self.flat.view_of(self.m, i).copy_(st["momentum_buffer"])
+                st["momentum_buffer"] = self.flat.view_of(self.m, i)
+            else:
+                self.flat.view_of(self.m, i).copy_(st["exp_avg"])
+                self.flat.view_of(self.v, i).copy_(st["exp_avg_sq"])
+                st["exp_avg"], st["exp_avg_sq"] = self.flat.view_of(self.m, i), self.flat.view_of(self.v, i)
+                self.steps = int(st["step"])
+
+
+def get_optimizer(model, optimizer_name="adam", lr=0.001, weight_decay=1e-4):
+    """Same factory signature as the reference (training_utils.py:311-331)."""
+    return FusedOptimizer(model, optimizer_name, lr=lr, weight_decay=weight_decay)
+
+
+def get_scheduler(optimizer, scheduler_name="step", step_size=20, gamma=0.1):
+    """training_utils.py:333-353"""
+    name = scheduler_name.lower()
+    if name == "step":
+        return torch.optim.lr_scheduler.StepLR(optimizer, step_size=step_size, gamma=gamma)
+    if name == "cosine":
+        return torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=step_size)
+    if name == "plateau":
+        return torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, mode="min", factor=gamma, patience=step_size)
+    raise ValueError(f"Unsupported scheduler: {scheduler_name}")
+
+
+# --------------------------------------------------------------------------------------
+# bucketed gradient all-reduce
+# --------------------------------------------------------------------------------------
+class GradBucketer:
+    """Splits the flat gradient buffer into contiguous buckets and all-reduces each bucket as soon as the
+    backward pass has produced the gradients of all its parameters (signalled through ``notify``), on a
+    side stream so that the collective overlaps the rest of backward.  Works on any backend
+    (``nccl`` = RCCL on the GPUs, ``gloo`` on CPU for the tests)."""
+
+    def __init__(self, flat, bucket_bytes=32 << 20, group=None, overlap=True):
+        self.flat = flat
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.on_gpu = flat.grad.is_cuda
+        self.overlap = overlap and self.on_gpu
+        self.stream = torch.cuda.Stream() if self.overlap else None
+        # parameters are produced roughly in reverse registration order during backward, so buckets are
+        # cut walking the flat buffer from its end
+        self.buckets = []  # (start, end) element ranges
+        self.bucket_of = {}
+        limit = max(1, bucket_bytes // 4)
+        end = flat.total
+        cur_hi = end
+        n = len(flat.params)
+        members = []
+        for i in range(n - 1, -1, -1):
+            members.append(i)
+            lo = flat.offsets[i]
+            if cur_hi - lo >= limit or i == 0:
+                b = len(self.buckets)
+                self.buckets.append((lo, cur_hi))
+                for j in members:
+                    self.bucket_of[id(flat.params[j])] = b
+                members = []
+                cur_hi = lo
+        self.sizes = [0] * len(self.buckets)
+        for p in flat.params:
+            self.sizes[self.bucket_of[id(p)]] += 1
+        self.reset()
+
+    def reset(self):
+        self.pending = list(self.sizes)
+        self.launched = [False] * len(self.buckets)
+        self.handles = []
+
+    def notify(self, p):
+        b = self.bucket_of.get(id(p))
+        if b is None or self.launched[b]:
+            return
+        self.pending[b] -= 1
+        if self.pending[b] <= 0:
+            self._launch(b)
+
+    def _launch(self, b):
+        self.launched[b] = True
+        if self.world == 1:
+            return
+        lo, hi = self.buckets[b]
+        view = self.flat.grad[lo:hi]
+        if self.overlap:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """Launch whatever was not signalled, wait for every collective; gradients then hold the SUM over
+        ranks (the optimizer folds the 1/world factor into its update)."""
+        for b in range(len(self.buckets)):
+            if not self.launched[b]:
+                self._launch(b)
+        for h in self.handles:
+            h.wait()
+        if self.overlap:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        self.handles = []
+
+
+def init_distributed(backend=None):
+    """Initialise torch.distributed from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT).  Returns (rank, local_rank, world)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+    return rank, local_rank, world
+
+
+def make_data_parallel(model, optimizer, bucket_mb=32, group=None, overlap=True):
+    """Broadcast rank 0's parameters and buffers, attach a GradBucketer to the optimizer and hook it
+    into the kernels' gradient-ready notifications.  The model object is used as is (no wrapper, so
+    state_dict keys carry no ``module.`` prefix)."""
+    flat = optimizer.flat
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world > 1:
+        dist.broadcast(flat.data, src=0, group=group)
+        for b in model.buffers():
+            dist.broadcast(b, src=0, group=group)
+        ops.bump_weights_epoch()
+    bucketer = GradBucketer(flat, bucket_bytes=bucket_mb << 20, group=group, overlap=overlap)
+    optimizer.bucketer = bucketer
+    optimizer.grad_scale = 1.0 / world
+    ops.set_grad_ready_hook(bucketer.notify)
+    return bucketer
+
+
+# --------------------------------------------------------------------------------------
+# criterion, epoch loops, checkpoints
+# --------------------------------------------------------------------------------------
+class FusedCrossEntropyLoss(nn.Module):
+    """nn.CrossEntropyLoss() replacement (mean reduction) on the fused HIP head; also records the arg-max
+    predictions and the number of correct ones of the last call in ``self.stats``."""
+
+    def __init__(self):
+        super().__init__()
+        self.stats = {}
+
+    def forward(self, output, target):
+        return ops.cross_entropy(output, target, self.stats)
+
+
+def _run_batch(model, data, target, criterion):
+    output = model(data)
+    loss = criterion(output, target.squeeze())
+    if isinstance(criterion, FusedCrossEntropyLoss):
+        correct = criterion.stats["correct"]
+    else:
+        pred = output.argmax(dim=1, keepdim=True)
+        correct = pred.eq(target.view_as(pred)).sum()
+    return output, loss, correct
+
+
+def train_epoch(model, train_loader, criterion, optimizer, device, epoch, use_amp=False, scaler=None, logger=None):
+    """Returns (average loss over batches, accuracy %), as the reference's train_epoch.  Loss and accuracy
+    are accumulated on the device and read back once per logging interval instead of three times per
+    batch.  `use_amp`/`scaler` are accepted for signature compatibility; precision is chosen by the
+    model's compute dtype."""
+    model.train()
+    total_loss = torch.zeros((), device=device)
+    correct = torch.zeros((), device=device, dtype=torch.int64)
+    total = 0
+    nb = 0
+    for batch_idx, (data, target) in enumerate(train_loader):
+        data, target = data.to(device, non_blocking=True), target.to(device, non_blocking=True)
+        optimizer.zero_grad()
+        _, loss, ncorrect = _run_batch(model, data, target, criterion)
+        loss.backward()
+        optimizer.step()
+        total_loss += loss.detach()
+        correct += ncorrect.reshape(()).to(torch.int64)
+        total += target.size(0)
+        nb += 1
+        if logger and (batch_idx + 1) % 100 == 0:
+            logger.info(f"Epoch {epoch} - Batch {batch_idx + 1}/{len(train_loader)} - Loss: {loss.item():.4f}, "
+                        f"Acc: {100. * correct.item() / total:.2f}%")
+    return total_loss.item() / max(nb, 1), 100. * correct.item() / max(total, 1)
+
+
+def validate_epoch(model, val_loader, criterion, device, epoch, use_amp=False, logger=None):
+    model.eval()
+    total_loss = torch.zeros((), device=device)
+    correct = torch.zeros((), device=device, dtype=torch.int64)
+    total = 0
+    nb = 0
+    with torch.no_grad():
+        for batch_idx, (data, target) in enumerate(val_loader):
+            data, target = data.to(device, non_blocking=True), target.to(device, non_blocking=True)
+            _, loss, ncorrect = _run_batch(model, data, target, criterion)
+            total_loss += loss
+            correct += ncorrect.reshape(()).to(torch.int64)
+            total += target.size(0)
+            nb += 1
+            if logger and (batch_idx + 1) % 50 == 0:
+                logger.info(f"Epoch {epoch} - Val Batch {batch_idx + 1}/{len(val_loader)} - Loss: {loss.item():.4f}, "
+                            f"Acc: {100. * correct.item() / total:.2f}%")
+    return total_loss.item() / max(nb, 1), 100. * correct.item() / max(total, 1)
+
+
+def save_checkpoint(model, optimizer, epoch, loss, save_path):
+    """Same dictionary as the reference (training_utils.py:212-219), written from rank 0 only."""
+    if dist.is_initialized() and dist.get_rank() != 0:
+        return
+    os.makedirs(os.path.dirname(save_path) or ".", exist_ok=True)
+    torch.save({"epoch": epoch, "model_state_dict": model.state_dict(),
+                "optimizer_state_dict": optimizer.state_dict(), "loss": loss}, save_path)
+
+
+def strip_module_prefix(state_dict):
+    """Checkpoints written under nn.DataParallel carry a ``module.`` prefix on every key."""
+    return {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+
+
+def load_checkpoint(model, optimizer, checkpoint_path):
+    """Returns the epoch to start from (training_utils.py:222-243); accepts DataParallel-prefixed keys."""
+    if not os.path.exists(checkpoint_path):
+        return 1
+    ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
+    model.load_state_dict(strip_module_prefix(ckpt["model_state_dict"]))
+    if optimizer is not None and "optimizer_state_dict" in ckpt:
+        optimizer.load_state_dict(ckpt["optimizer_state_dict"])
+    ops.bump_weights_epoch()
+    return ckpt["epoch"] + 1
