@@ -111,6 +111,20 @@ int vc_dropout_fwd(int dtype, const void* x, void* out, uint8_t* mask, int64_t n
                    vc_stream_t stream);
 int vc_dropout_bwd(int dtype, const void* dy, const uint8_t* mask, void* dx, int64_t n, float p, vc_stream_t stream);
 
+/* timm's DropPath (stochastic depth) inside the Swin blocks; backward applies the same call to the gradient */
+int vc_drop_path(int dtype, const void* x, void* out, int64_t n, int64_t elems_per_sample, float p, uint64_t seed,
+                 vc_stream_t stream);
+
+/* ---- Swin-T window attention / patch merging (timm swin_tiny_patch4_window7_224 behind
+ * model_components.py:254, 412).  qkv [B*H*W][3C] in token order; window partition, cyclic shift, relative
+ * position bias gather, shift mask, softmax and P.V are one kernel; head_dim is 32, window <= 7. */
+int vc_window_attn_fwd(int dtype, const void* qkv, const float* bias_table, void* out, int B, int H, int W, int C,
+                       int heads, int ws, int shift, float scale, vc_stream_t stream);
+int vc_window_attn_bwd(int dtype, const void* qkv, const void* dout, const float* bias_table, void* dqkv,
+                       float* dbias_table, int B, int H, int W, int C, int heads, int ws, int shift, float scale,
+                       vc_stream_t stream);
+int vc_patch_merge(int dtype, const void* in, void* out, int B, int H, int W, int C, int inverse, vc_stream_t stream);
+
 /* ---- LSTM cell (gate order i,f,g,o; nn.LSTM at model_components.py:209-214, 482-483) -------------- */
 int vc_lstm_cell_fwd(int dtype, const float* gates_x, int ldx, const float* gates_h, const float* c_prev, void* h_out,
                      int ldh, float* c_out, float* act_out, int B, int H, vc_stream_t stream);

@@ -1,0 +1,221 @@
+"""GPU parity of the bandwidth-bound kernels (BatchNorm with groups, pooling, LayerNorm, cross-entropy,
+fused optimizers, dropout) against plain PyTorch fp32 on the CPU, through the autograd wrappers / C ABI.
+
+Tolerances: float32 path 2e-5 (relative to the largest magnitude), bfloat16 path 2e-2 (storage rounding).
+"""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import golden_util as G
+
+pytestmark = pytest.mark.gpu
+DTYPES = [torch.float32, torch.bfloat16]
+IDS = ["f32", "bf16"]
+
+
+def tol(dt):
+    return 2e-5 if dt == torch.float32 else 2e-2
+
+
+def rnd(dt, *shape, seed=0):
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+    return x.bfloat16().float() if dt == torch.bfloat16 else x
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=IDS)
+@pytest.mark.parametrize("shape,groups", [((6, 1, 5, 7, 24), 3), ((8, 1, 1, 1, 96), 2), ((4, 3, 6, 6, 32), 1),
+                                          ((6, 1, 3, 3, 2304), 2)])
+@pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False)])
+def test_batchnorm_groups(cuda, dt, shape, groups, relu, res):
+    """Training-mode BN over G groups of rows == the reference's per-time-step loop: G separate BN calls in
+    order, running stats updated G times."""
+    from video_classification_amd import ops
+    C = shape[-1]
+    x = rnd(dt, *shape, seed=1) * 2 + 0.5
+    if dt == torch.bfloat16:
+        # keep the input exactly representable: a rounded input would flip ReLU decisions of outputs within
+        # 2^-9 of zero, and each flip changes that element's gradient by O(1)
+        x = x.bfloat16().float()
+    r = rnd(dt, *shape, seed=2) if res else None
+    dy = rnd(dt, *shape, seed=3)
+    bn_ref = nn.BatchNorm1d(C, momentum=0.01)
+    with torch.no_grad():
+        bn_ref.weight.copy_(torch.randn(C, generator=torch.Generator().manual_seed(4)))
+        bn_ref.bias.copy_(torch.randn(C, generator=torch.Generator().manual_seed(5)))
+    bn_mine = nn.BatchNorm1d(C, momentum=0.01)
+    bn_mine.load_state_dict(bn_ref.state_dict())
+    bn_mine.to(cuda)
+    # reference: per-group BN on [rows, C]
+    xr = x.clone().requires_grad_(True)
+    rr = r.clone().requires_grad_(True) if res else None
+    n = shape[0] // groups
+    outs = []
+    for g in range(groups):
+        o = bn_ref(xr[g * n:(g + 1) * n].reshape(-1, C))
+        if res:
+            o = o + rr[g * n:(g + 1) * n].reshape(-1, C)
+        outs.append(F.relu(o) if relu else o)
+    out_r = torch.cat(outs).reshape(shape)
+    out_r.backward(dy)
+    xm = x.to(cuda, dt).requires_grad_(True)
+    rm = r.to(cuda, dt).requires_grad_(True) if res else None
+    out_m = ops.batch_norm(xm, bn_mine, groups, relu=relu, residual=rm)
+    out_m.backward(dy.to(cuda, dt))
+    t = tol(dt)
+    assert G.max_rel(out_m.float().cpu(), out_r.detach()) < t
+    assert G.max_rel(xm.grad.float().cpu(), xr.grad) < 2 * t
+    if res:
+        assert G.max_rel(rm.grad.float().cpu(), rr.grad) < t
+    assert G.max_rel(bn_mine.weight.grad.cpu(), bn_ref.weight.grad) < 2 * t
+    assert G.max_rel(bn_mine.bias.grad.cpu(), bn_ref.bias.grad) < 2 * t
+    assert G.max_rel(bn_mine.running_mean.cpu(), bn_ref.running_mean) < t
+    assert G.max_rel(bn_mine.running_var.cpu(), bn_ref.running_var) < t
+    assert int(bn_mine.num_batches_tracked) == groups
+    # eval mode uses the running statistics
+    bn_ref.eval()
+    bn_mine.eval()
+    with torch.no_grad():
+        oe_r = bn_ref(x.reshape(-1, C)).reshape(shape)
+        oe_m = ops.batch_norm(x.to(cuda, dt), bn_mine, groups)
+    assert G.max_rel(oe_m.float().cpu(), oe_r) < t
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=IDS)
+@pytest.mark.parametrize("k,s,p,H,W", [(3, 2, 1, 14, 14), (3, 2, 1, 9, 11), (2, 2, 0, 8, 6), (2, 2, 0, 7, 7)])
+def test_maxpool(cuda, dt, k, s, p, H, W):
+    from video_classification_amd import ops
+    x = F.relu(rnd(dt, 3, 16, H, W, seed=7))  # post-ReLU input: many exact ties at zero
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, k, s, p)
+    dy = rnd(dt, *yr.shape, seed=8)
+    yr.backward(dy)
+    xm = x.permute(0, 2, 3, 1).contiguous().to(cuda, dt).requires_grad_(True)
+    ym = ops.max_pool2d(xm, k, s, p)
+    ym.backward(dy.permute(0, 2, 3, 1).contiguous().to(cuda, dt))
+    assert torch.equal(ym.float().cpu().permute(0, 3, 1, 2), yr.detach())
+    # ties at zero may pick different window positions; the ReLU in front zeroes those gradients anyway
+    mask = (x > 0).float()
+    assert G.max_rel(xm.grad.float().cpu().permute(0, 3, 1, 2) * mask, xr.grad * mask) < tol(dt)
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=IDS)
+def test_global_avgpool(cuda, dt):
+    from video_classification_amd import ops
+    x = rnd(dt, 5, 49, 64, seed=9)
+    xr = x.clone().requires_grad_(True)
+    yr = xr.mean(1)
+    dy = rnd(dt, 5, 64, seed=10)
+    yr.backward(dy)
+    xm = x.to(cuda, dt).requires_grad_(True)
+    ym = ops.global_avg_pool(xm)
+    ym.backward(dy.to(cuda, dt))
+    assert G.max_rel(ym.float().cpu(), yr.detach()) < tol(dt)
+    assert G.max_rel(xm.grad.float().cpu(), xr.grad) < tol(dt)
+
+
+@pytest.mark.parametrize("B,C", [(4, 101), (37, 101), (3, 7)])
+def test_cross_entropy_head(cuda, B, C):
+    from video_classification_amd import ops
+    logits = torch.randn(B, 104, generator=torch.Generator().manual_seed(11)) * 3
+    target = torch.randint(0, C, (B, 1), generator=torch.Generator().manual_seed(12))
+    lr = logits[:, :C].clone().requires_grad_(True)
+    loss_r = F.cross_entropy(lr, target.squeeze(1))
+    loss_r.backward()
+    lm = logits.to(cuda).requires_grad_(True)
+    stats = {}
+    loss_m = ops.cross_entropy(lm[:, :C], target.to(cuda), stats)
+    loss_m.backward()
+    assert abs(loss_m.item() - loss_r.item()) < 1e-5
+    assert G.max_rel(lm.grad[:, :C].cpu(), lr.grad) < 1e-5
+    assert torch.all(lm.grad[:, C:] == 0)
+    assert torch.equal(stats["pred"].cpu(), lr.argmax(1))
+    assert int(stats["correct"]) == int((lr.argmax(1) == target.squeeze(1)).sum())
+
+
+def test_argmax_ties_take_first_index(cuda):
+    from video_classification_amd import ops
+    logits = torch.zeros(2, 104)
+    logits[0, 5] = logits[0, 70] = 2.0
+    logits[1, 100] = logits[1, 3] = 1.0
+    stats = {}
+    ops.cross_entropy(logits.to(cuda)[:, :101], torch.tensor([5, 3]).to(cuda), stats)
+    assert stats["pred"].tolist() == [5, 3]
+    assert torch.equal(stats["pred"].cpu(), logits[:, :101].argmax(1))
+
+
+@pytest.mark.parametrize("name,kw", [("adam", dict(lr=1e-3, weight_decay=1e-4)), ("adamw", dict(lr=1e-3, weight_decay=1e-2)),
+                                     ("sgd", dict(lr=1e-2, weight_decay=1e-4))])
+def test_fused_optimizers_match_torch(cuda, name, kw):
+    """Three steps of the fused flat-buffer optimizer against torch.optim on the CPU (training_utils.py:324-329)."""
+    from video_classification_amd import trainer as TR
+    torch.manual_seed(0)
+    ref = nn.Sequential(nn.Linear(13, 7), nn.Linear(7, 5))
+    mine = nn.Sequential(nn.Linear(13, 7), nn.Linear(7, 5))
+    mine.load_state_dict(ref.state_dict())
+    mine.to(cuda)
+    if name == "adam":
+        opt_r = torch.optim.Adam(ref.parameters(), **kw)
+    elif name == "adamw":
+        opt_r = torch.optim.AdamW(ref.parameters(), **kw)
+    else:
+        opt_r = torch.optim.SGD(ref.parameters(), momentum=0.9, **kw)
+    opt_m = TR.FusedOptimizer(mine, name, **kw)
+    for step in range(3):
+        opt_m.zero_grad()
+        for pr, pm in zip(ref.parameters(), mine.parameters()):
+            g = torch.randn(pr.shape, generator=torch.Generator().manual_seed(100 + step))
+            pr.grad = g.clone()
+            pm.grad.copy_(g)
+        opt_r.step()
+        opt_m.step()
+    for pr, pm in zip(ref.parameters(), mine.parameters()):
+        assert (pm.detach().cpu() - pr.detach()).abs().max().item() < 2e-6
+    # optimizer state has torch's layout (checkpoint compatibility)
+    sd = opt_m.state_dict()
+    assert set(sd.keys()) == {"state", "param_groups"}
+    if name != "sgd":
+        assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=IDS)
+def test_dropout_statistics_and_backward(cuda, dt):
+    from video_classification_amd import ops
+    x = torch.ones(64, 1024, device=cuda, dtype=dt, requires_grad=True)
+    ops.manual_seed(1)
+    y = ops.dropout(x, 0.3, True)
+    keep = (y != 0).float().mean().item()
+    assert abs(keep - 0.7) < 0.01
+    assert torch.allclose(y[y != 0].float(), torch.tensor(1 / 0.7), rtol=1e-2)
+    y.sum().backward()
+    assert torch.equal(x.grad != 0, y != 0)
+    y2 = ops.dropout(x, 0.3, True)
+    assert not torch.equal(y2 != 0, y != 0)  # a new mask every call
+    assert ops.dropout(x, 0.3, False) is x
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=IDS)
+@pytest.mark.parametrize("M,C", [(50, 96), (7, 768), (300, 384)])
+def test_layernorm(cuda, dt, M, C):
+    from video_classification_amd import ops
+    x = rnd(dt, M, C, seed=20) * 3 + 1
+    dy = rnd(dt, M, C, seed=21)
+    ln_r = nn.LayerNorm(C)
+    with torch.no_grad():
+        ln_r.weight.copy_(torch.randn(C, generator=torch.Generator().manual_seed(22)))
+        ln_r.bias.copy_(torch.randn(C, generator=torch.Generator().manual_seed(23)))
+    ln_m = nn.LayerNorm(C)
+    ln_m.load_state_dict(ln_r.state_dict())
+    ln_m.to(cuda)
+    xr = x.clone().requires_grad_(True)
+    yr = ln_r(xr)
+    yr.backward(dy)
+    xm = x.to(cuda, dt).requires_grad_(True)
+    ym = ops.layer_norm(xm, ln_m)
+    ym.backward(dy.to(cuda, dt))
+    t = tol(dt)
+    assert G.max_rel(ym.float().cpu(), yr.detach()) < t
+    assert G.max_rel(xm.grad.float().cpu(), xr.grad) < 2 * t
+    assert G.max_rel(ln_m.weight.grad.cpu(), ln_r.weight.grad) < 2 * t
+    assert G.max_rel(ln_m.bias.grad.cpu(), ln_r.bias.grad) < 2 * t

@@ -37,6 +37,20 @@ __global__ void dropout_bwd_kernel(const T* __restrict__ dy, const uint8_t* __re
     dx[i] = from_f32<T>(mask[i] ? to_f32(dy[i]) * scale : 0.f);
 }
 
+// stochastic depth: the whole residual branch of a sample is kept (scaled by 1/(1-p)) or zeroed; the keep
+// decision is a pure function of (seed, sample), so backward re-applies the same kernel to the gradient
+template <typename T>
+__global__ void drop_path_kernel(const T* __restrict__ x, T* __restrict__ out, int64_t n8, int64_t chunks_per_sample,
+                                 uint32_t thresh, float scale, uint64_t seed) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    const bool keep = mix_u32(seed, (uint64_t)(i / chunks_per_sample)) >= thresh;
+    F8 v = load8(x + i * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v.v[j] = keep ? v.v[j] * scale : 0.f;
+    store8(out + i * 8, v);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // TCG-LSTM fusion.  Layouts are time-major: h_s [T][B][2H], h_l [Tl][B][H].
 // Linear interpolation follows F.interpolate(mode='linear', align_corners=False):
@@ -288,6 +302,20 @@ int vc_dropout_bwd(int dtype, const void* dy, const uint8_t* mask, void* dx, int
              hipLaunchKernelGGL((dropout_bwd_kernel<T>), dim3(ew_grid(n)), dim3(NTHR), 0, stream, (const T*)dy, mask,
                                 (T*)dx, n, scale);)
   VC_LAUNCH_CHECK("vc_dropout_bwd");
+  return VC_OK;
+}
+
+int vc_drop_path(int dtype, const void* x, void* out, int64_t n, int64_t elems_per_sample, float p, uint64_t seed,
+                 hipStream_t stream) {
+  VC_CHECK_ARG(x && out && n > 0 && p >= 0.f && p < 1.f, "vc_drop_path: bad argument");
+  VC_CHECK_SHAPE(n % 8 == 0 && elems_per_sample % 8 == 0 && elems_per_sample > 0 && n % elems_per_sample == 0,
+                 "vc_drop_path: sizes must be multiples of 8 and of the per-sample size");
+  const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
+  const float scale = 1.f / (1.f - p);
+  DISPATCH_T(dtype, "vc_drop_path",
+             hipLaunchKernelGGL((drop_path_kernel<T>), dim3(ew_grid(n / 8)), dim3(NTHR), 0, stream, (const T*)x,
+                                (T*)out, n / 8, elems_per_sample / 8, thresh, scale, seed);)
+  VC_LAUNCH_CHECK("vc_drop_path");
   return VC_OK;
 }
 

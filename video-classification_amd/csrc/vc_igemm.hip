@@ -19,6 +19,8 @@
 //   * naive kernels (any element type): one thread per output element, fp32 accumulate.
 //     They are the dtype = fp32 implementation (exact-order-independent fp32 reference
 //     grade) and the on-device cross-check for the MFMA kernels.
+#include <stdlib.h>
+
 #include "vc_common.h"
 
 namespace {
@@ -103,14 +105,30 @@ __device__ __forceinline__ void xcd_remap(int& logical) {
   logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int MODE>
+// 64 bytes of zeros: the source of LDS-DMA lanes whose tap is padding / out of range
+__device__ __attribute__((aligned(64))) const uint32_t vc_zero_src[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// One wave-instruction of LDS-DMA: every lane moves 16 bytes from its own global address to
+// lds_base + lane*16 (the destination is lane-linear by construction of the hardware).
+__device__ __forceinline__ void glds16(const void* g, bf16* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+
+// GLDS = true : tiles are staged global -> LDS by LDS-DMA (no VGPR round trip, no ds_write); the XOR
+//               swizzle of the LDS image is applied to each lane's SOURCE address.
+// GLDS = false: register-staged variant (global_load -> VGPR -> ds_write), kept for A/B measurements.
+template <int MODE, bool GLDS>
 __global__ __launch_bounds__(NTHR, 2) void igemm_nt_bf16_kernel(ConvGeom g, const bf16* __restrict__ src,
                                                                 const bf16* __restrict__ wgt,
                                                                 const float* __restrict__ bias, void* __restrict__ out,
                                                                 int relu, int out_f32, int beta) {
-  __shared__ __attribute__((aligned(16))) bf16 smem[2 * (BM + BN) * BK];
+  __shared__ __attribute__((aligned(1024))) bf16 smem[2 * (BM + BN) * BK];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int tiles_n = (g.Co + BN - 1) / BN;
   int logical;
@@ -118,7 +136,10 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_bf16_kernel(ConvGeom g, cons
   const int tile_m = logical / tiles_n, tile_n = logical - tile_m * tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-  const int lrow = tid >> 3, lchunk = tid & 7;
+  // staging role of this thread: LDS row lrow (+32*i), physical 16-byte slot pchunk of the row,
+  // which holds logical k-chunk lchunk (same XOR for the four rows: 32*i does not change (row>>1)&7)
+  const int lrow = tid >> 3, pchunk = tid & 7;
+  const int lchunk = pchunk ^ ((lrow >> 1) & 7);
   RowPos rp[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) rp[i] = decode_row<MODE>(g, m0 + lrow + 32 * i);
@@ -126,6 +147,26 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_bf16_kernel(ConvGeom g, cons
   const int nk = (g.K + BK - 1) / BK;
   bf16x8 areg[4], wreg[4];
 
+  auto stage_dma = [&](int kt, int buf) {
+    const int kc = kt * (BK / 8) + lchunk;
+    const bool kvalid = kc * 8 < g.K;
+    int rd, rh, rw, c;
+    decode_chunk(g, kc, rd, rh, rw, c);
+    bf16* sA = smem + buf * (BM + BN) * BK;
+    bf16* sW = sA + BM * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const void* asrc = vc_zero_src;
+      const int pix = gather_pixel<MODE>(g, rp[i], rd, rh, rw);
+      if (kvalid && pix >= 0) asrc = src + (size_t)pix * g.ldi + c;
+      const void* wsrc = vc_zero_src;
+      const int co = n0 + lrow + 32 * i;
+      if (kvalid && co < g.Co) wsrc = wgt + (size_t)co * g.K + kc * 8;
+      // this wave's instruction fills rows [32*i + 8*wave, +8): 8 rows x 128 B = 64 lanes x 16 B
+      glds16(asrc, sA + (32 * i + 8 * wave) * BK);
+      glds16(wsrc, sW + (32 * i + 8 * wave) * BK);
+    }
+  };
   auto load_tile = [&](int kt) {
     const int kc = kt * (BK / 8) + lchunk;
     const bool kvalid = kc * 8 < g.K;
@@ -149,8 +190,8 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_bf16_kernel(ConvGeom g, cons
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = lrow + 32 * i;
-      *reinterpret_cast<bf16x8*>(sA + nt_lds_off(row, lchunk)) = areg[i];
-      *reinterpret_cast<bf16x8*>(sW + nt_lds_off(row, lchunk)) = wreg[i];
+      *reinterpret_cast<bf16x8*>(sA + row * BK + pchunk * 8) = areg[i];
+      *reinterpret_cast<bf16x8*>(sW + row * BK + pchunk * 8) = wreg[i];
     }
   };
 
@@ -160,13 +201,21 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_bf16_kernel(ConvGeom g, cons
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  load_tile(0);
-  store_tile(0);
+  if (GLDS) {
+    stage_dma(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    load_tile(0);
+    store_tile(0);
+  }
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) load_tile(kt + 1);
+    if (kt + 1 < nk) {
+      if (GLDS) stage_dma(kt + 1, buf ^ 1);
+      else load_tile(kt + 1);
+    }
     const bf16* sA = smem + buf * (BM + BN) * BK;
     const bf16* sW = sA + BM * BK;
 #pragma unroll
@@ -184,7 +233,11 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_bf16_kernel(ConvGeom g, cons
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) store_tile(buf ^ 1);
+    if (GLDS) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (kt + 1 < nk) {
+      store_tile(buf ^ 1);
+    }
     __syncthreads();
   }
 
@@ -252,10 +305,6 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_bf16_kernel(ConvGeom g, cons
 // TN kernel (weight gradient).  g is the FORWARD geometry (src = x).
 // ----------------------------------------------------------------------------
 __device__ __forceinline__ int tn_swz(int row) { return (row & 3) | ((row >> 1) & 4); }
-// element offset of 16-byte chunk `chunk` (0..15) of pixel row `row` in a [64][128] tile
-__device__ __forceinline__ int tn_lds_off(int row, int chunk) {
-  return row * 128 + ((((chunk >> 1) ^ tn_swz(row)) << 1) | (chunk & 1)) * 8;
-}
 // element offset of the 8-byte piece p (0..3) of 16-column block `blk` (0..7) of row `row`
 __device__ __forceinline__ int tn_tr_off(int row, int blk, int p) {
   return row * 128 + ((blk ^ tn_swz(row)) << 4) + p * 4;
@@ -280,13 +329,15 @@ __device__ __forceinline__ bf16x8 tr_read_frag(const bf16* tile, int krow0, int 
   return u.v;
 }
 
+template <bool GLDS>
 __global__ __launch_bounds__(NTHR, 2) void igemm_tn_wgrad_bf16_kernel(ConvGeom g, const bf16* __restrict__ x,
                                                                       const bf16* __restrict__ dy, int ldy,
                                                                       float* __restrict__ dw, int m_per_split,
                                                                       int ntiles, int tiles_col) {
-  __shared__ __attribute__((aligned(16))) bf16 smem[2 * 2 * BK * 128];
+  __shared__ __attribute__((aligned(1024))) bf16 smem[2 * 2 * BK * 128];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave >> 1, wm = wave & 1;  // wn: co half, wm: col half
   int logical;
   xcd_remap(logical);
@@ -296,7 +347,10 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_tn_wgrad_bf16_kernel(ConvGeom g
   const int m_begin = split * m_per_split;
   const int m_end = min(g.M, m_begin + m_per_split);
 
-  const int lchunk = tid & 15, lrow = tid >> 4;
+  // staging role: LDS row lrow (+16*i), physical 16-byte slot pchunk, which holds logical column chunk
+  // lchunk (32-byte blocks are XOR-swizzled by row; 16*i leaves the row's swizzle unchanged)
+  const int pchunk = tid & 15, lrow = tid >> 4;
+  const int lchunk = ((((pchunk >> 1) ^ tn_swz(lrow)) << 1) | (pchunk & 1));
   // this thread's gather column is fixed for the whole kernel
   const int col = col0 + lchunk * 8;
   const bool colvalid = col < g.K;
@@ -306,6 +360,27 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_tn_wgrad_bf16_kernel(ConvGeom g
   const bool covalid = co_ld < g.Co;
 
   bf16x8 xreg[4], yreg[4];
+  auto stage_dma = [&](int mt, int buf) {
+    bf16* sY = smem + buf * (2 * BK * 128);
+    bf16* sX = sY + BK * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = mt + lrow + 16 * i;
+      const void* ysrc = vc_zero_src;
+      const void* xsrc = vc_zero_src;
+      if (m < m_end) {
+        if (covalid) ysrc = dy + (size_t)m * ldy + co_ld;
+        if (colvalid) {
+          const RowPos rp = decode_row<0>(g, m);
+          const int pix = gather_pixel<0>(g, rp, rd, rh, rw);
+          if (pix >= 0) xsrc = x + (size_t)pix * g.ldi + c;
+        }
+      }
+      // this wave's instruction fills rows [16*i + 4*wave, +4): 4 rows x 256 B
+      glds16(ysrc, sY + (16 * i + 4 * wave) * 128);
+      glds16(xsrc, sX + (16 * i + 4 * wave) * 128);
+    }
+  };
   auto load_tile = [&](int mt) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -329,8 +404,8 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_tn_wgrad_bf16_kernel(ConvGeom g
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = lrow + 16 * i;
-      *reinterpret_cast<bf16x8*>(sY + tn_lds_off(row, lchunk)) = yreg[i];
-      *reinterpret_cast<bf16x8*>(sX + tn_lds_off(row, lchunk)) = xreg[i];
+      *reinterpret_cast<bf16x8*>(sY + row * 128 + pchunk * 8) = yreg[i];
+      *reinterpret_cast<bf16x8*>(sX + row * 128 + pchunk * 8) = xreg[i];
     }
   };
 
@@ -341,14 +416,22 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_tn_wgrad_bf16_kernel(ConvGeom g
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (m_begin < m_end) {
-    load_tile(m_begin);
-    store_tile(0);
+    if (GLDS) {
+      stage_dma(m_begin, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      load_tile(m_begin);
+      store_tile(0);
+    }
   }
   __syncthreads();
   int buf = 0;
   for (int mt = m_begin; mt < m_end; mt += BK) {
     const bool more = mt + BK < m_end;
-    if (more) load_tile(mt + BK);
+    if (more) {
+      if (GLDS) stage_dma(mt + BK, buf ^ 1);
+      else load_tile(mt + BK);
+    }
     const bf16* sY = smem + buf * (2 * BK * 128);
     const bf16* sX = sY + BK * 128;
 #pragma unroll
@@ -365,7 +448,11 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_tn_wgrad_bf16_kernel(ConvGeom g
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], xf[j], acc[i][j], 0, 0, 0);
     }
-    if (more) store_tile(buf ^ 1);
+    if (GLDS) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (more) {
+      store_tile(buf ^ 1);
+    }
     __syncthreads();
     buf ^= 1;
   }
@@ -520,14 +607,27 @@ int fill_geom(ConvGeom& g, const int* d, int mode, const char* who) {
   return VC_OK;
 }
 
+// VC_IGEMM_STAGE=reg selects the register-staged variants (A/B measurements); default is LDS-DMA.
+bool use_glds() {
+  static const int v = [] {
+    const char* e = getenv("VC_IGEMM_STAGE");
+    return (e && strcmp(e, "reg") == 0) ? 0 : 1;
+  }();
+  return v != 0;
+}
+
 template <int MODE>
 int launch_nt(const ConvGeom& g, int dtype, const void* src, const void* wgt, const float* bias, void* out, int relu,
               int out_f32, int beta, hipStream_t stream, const char* who) {
   if (dtype == VC_BF16) {
     VC_CHECK_SHAPE(g.Ci % 8 == 0, "%s: bf16 path needs source channels %% 8 == 0 (got %d)", who, g.Ci);
     const int tiles = ceil_div(g.M, BM) * ceil_div(g.Co, BN);
-    hipLaunchKernelGGL((igemm_nt_bf16_kernel<MODE>), dim3(tiles), dim3(NTHR), 0, stream, g, (const bf16*)src,
-                       (const bf16*)wgt, bias, out, relu, out_f32, beta);
+    if (use_glds())
+      hipLaunchKernelGGL((igemm_nt_bf16_kernel<MODE, true>), dim3(tiles), dim3(NTHR), 0, stream, g, (const bf16*)src,
+                         (const bf16*)wgt, bias, out, relu, out_f32, beta);
+    else
+      hipLaunchKernelGGL((igemm_nt_bf16_kernel<MODE, false>), dim3(tiles), dim3(NTHR), 0, stream, g,
+                         (const bf16*)src, (const bf16*)wgt, bias, out, relu, out_f32, beta);
   } else if (dtype == VC_F32) {
     const int64_t total = (int64_t)g.M * g.Co;
     hipLaunchKernelGGL((conv_naive_kernel<float, MODE>), dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, stream,
@@ -590,8 +690,12 @@ int vc_conv_wgrad(const int* desc, int dtype, const void* x, int ldx, const void
     if (splits < 1) splits = 1;
     int mps = ceil_div(ceil_div(g.M, splits), BK) * BK;
     splits = ceil_div(g.M, mps);
-    hipLaunchKernelGGL(igemm_tn_wgrad_bf16_kernel, dim3(ntiles * splits), dim3(NTHR), 0, stream, g, (const bf16*)x,
-                       (const bf16*)dy, ldy_, dw_packed, mps, ntiles, tiles_col);
+    if (use_glds())
+      hipLaunchKernelGGL((igemm_tn_wgrad_bf16_kernel<true>), dim3(ntiles * splits), dim3(NTHR), 0, stream, g,
+                         (const bf16*)x, (const bf16*)dy, ldy_, dw_packed, mps, ntiles, tiles_col);
+    else
+      hipLaunchKernelGGL((igemm_tn_wgrad_bf16_kernel<false>), dim3(ntiles * splits), dim3(NTHR), 0, stream, g,
+                         (const bf16*)x, (const bf16*)dy, ldy_, dw_packed, mps, ntiles, tiles_col);
   } else if (dtype == VC_BF16) {
     const int64_t total = (int64_t)g.Co * g.K;
     hipLaunchKernelGGL((wgrad_naive_kernel<bf16>), dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, stream, g,

@@ -663,7 +663,37 @@ class _TCGInputs(torch.autograd.Function):
 
 
 def tcg_inputs(g, c, down, dtype):
+    if c.dim() == 4 and c.stride(2) == 0:
+        c = c[:, :, :1]  # k identical copies (an expanded view): their mean is any one of them
     return _TCGInputs.apply(g, c, down, dtype)
+
+
+class _DropPath(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, samples):
+        import ctypes
+        x = x.contiguous()
+        _dropout_seed[0] = (_dropout_seed[0] * 6364136223846793005 + 1442695040888963407) & 0x7FFFFFFFFFFFFFFF
+        ctx.args = (float(p), ctypes.c_uint64(_dropout_seed[0]), x.numel() // samples)
+        out = torch.empty_like(x)
+        L.call("vc_drop_path", L.dtype_code(x.dtype), L.ptr(x), L.ptr(out), L.i64(x.numel()), L.i64(ctx.args[2]),
+               ctx.args[0], ctx.args[1], L.stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        L.call("vc_drop_path", L.dtype_code(dy.dtype), L.ptr(dy), L.ptr(dx), L.i64(dy.numel()), L.i64(ctx.args[2]),
+               ctx.args[0], ctx.args[1], L.stream())
+        return dx, None, None
+
+
+def drop_path(x, p, training, samples):
+    """Stochastic depth on a residual branch: x holds `samples` equal-sized contiguous samples."""
+    if not training or p <= 0.0:
+        return x
+    return _DropPath.apply(x, p, samples)
 
 
 class _TCGFuse(torch.autograd.Function):
@@ -731,3 +761,115 @@ class _TCGFuse(torch.autograd.Function):
 
 def tcg_fuse(hs, hl, gate_linear):
     return _TCGFuse.apply(hs, hl, gate_linear.weight, gate_linear.bias)
+
+
+# ----------------------------------------------------------------------------------------------
+# Swin-T pieces: LayerNorm, GELU, shifted-window attention, patch merging
+# ----------------------------------------------------------------------------------------------
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        _require_cuda(x, "layer_norm")
+        x = x.contiguous()
+        C = x.shape[-1]
+        M = x.numel() // C
+        out = torch.empty_like(x)
+        stat = torch.empty(2, M, device=x.device, dtype=torch.float32)
+        L.call("vc_layernorm_fwd", L.dtype_code(x.dtype), L.ptr(x), L.ptr(weight.detach()), L.ptr(bias.detach()),
+               L.ptr(out), L.ptr(stat[0]), L.ptr(stat[1]), M, C, float(eps), L.stream())
+        ctx.weight, ctx.bias = weight, bias
+        ctx.save_for_backward(x, stat)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, stat = ctx.saved_tensors
+        C = x.shape[-1]
+        M = x.numel() // C
+        dout = cast(dout.contiguous(), x.dtype)
+        dx = torch.empty_like(x)
+        w, b = ctx.weight, ctx.bias
+        L.call("vc_layernorm_bwd", L.dtype_code(x.dtype), L.ptr(x), L.ptr(dout), L.ptr(w.detach()), L.ptr(stat[0]),
+               L.ptr(stat[1]), L.ptr(dx), L.ptr(_grad_buf(w)), L.ptr(_grad_buf(b)), M, C, L.stream())
+        _ready(w, b)
+        return dx, None, None, None
+
+
+def layer_norm(x, ln):
+    """ln: nn.LayerNorm holding weight / bias / eps; normalises the last dimension."""
+    return _LayerNorm.apply(x, ln.weight, ln.bias, ln.eps)
+
+
+class _Gelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return elementwise(3, x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return elementwise(4, cast(dy.contiguous(), x.dtype), x)
+
+
+def gelu(x):
+    return _Gelu.apply(x)
+
+
+class _WindowAttention(torch.autograd.Function):
+    """qkv [B*H*W, 3C] (token order, no window partition / roll materialised) -> attention output [B*H*W, C]."""
+
+    @staticmethod
+    def forward(ctx, qkv, bias_table, B, H, W, heads, ws, shift):
+        _require_cuda(qkv, "window_attention")
+        qkv = qkv.contiguous()
+        C = qkv.shape[-1] // 3
+        scale = (C // heads) ** -0.5
+        out = torch.empty(qkv.shape[0], C, device=qkv.device, dtype=qkv.dtype)
+        L.call("vc_window_attn_fwd", L.dtype_code(qkv.dtype), L.ptr(qkv), L.ptr(bias_table.detach()), L.ptr(out), B, H, W,
+               C, heads, ws, shift, float(scale), L.stream())
+        ctx.meta = (B, H, W, C, heads, ws, shift, scale)
+        ctx.table = bias_table
+        ctx.save_for_backward(qkv)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (qkv,) = ctx.saved_tensors
+        B, H, W, C, heads, ws, shift, scale = ctx.meta
+        dout = cast(dout.contiguous(), qkv.dtype)
+        dqkv = torch.empty_like(qkv)
+        tb = ctx.table
+        dtb = _grad_buf(tb) if tb.requires_grad else None
+        L.call("vc_window_attn_bwd", L.dtype_code(qkv.dtype), L.ptr(qkv), L.ptr(dout), L.ptr(tb.detach()), L.ptr(dqkv),
+               L.ptr(dtb), B, H, W, C, heads, ws, shift, float(scale), L.stream())
+        _ready(tb)
+        return dqkv, None, None, None, None, None, None, None
+
+
+def window_attention(qkv, bias_table, B, H, W, heads, ws, shift):
+    return _WindowAttention.apply(qkv, bias_table, B, H, W, heads, ws, shift)
+
+
+class _PatchMerge(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        B, H, W, C = x.shape
+        out = torch.empty(B, H // 2, W // 2, 4 * C, device=x.device, dtype=x.dtype)
+        L.call("vc_patch_merge", L.dtype_code(x.dtype), L.ptr(x), L.ptr(out), B, H, W, C, 0, L.stream())
+        ctx.shape = (B, H, W, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, H, W, C = ctx.shape
+        dy = dy.contiguous()
+        dx = torch.empty(B, H, W, C, device=dy.device, dtype=dy.dtype)
+        L.call("vc_patch_merge", L.dtype_code(dy.dtype), L.ptr(dy), L.ptr(dx), B, H, W, C, 1, L.stream())
+        return dx
+
+
+def patch_merge(x):
+    """[B,H,W,C] -> [B,H/2,W/2,4C] with timm's PatchMerging channel order."""
+    return _PatchMerge.apply(x)
