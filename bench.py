@@ -39,6 +39,43 @@ import torch.distributed as dist  # noqa: E402
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X
 
 
+def build_workload(args, M, S, oracle=False):
+    """(model, clip shape per GPU, workload description) for --model; `oracle` builds the CPU restatement."""
+    O = None
+    if oracle:
+        from oracle import torch_oracle as O
+    B = args.batch
+    if args.model == "resnetcrnn":
+        cfg = model_config(args)
+        model = (O or M).ResNetCRNNModel(cfg)
+        return model, (B, 16, 3, 224, 224), (
+            f"ResNetCRNN training step: ResCNNEncoder({args.arch}, 1024/768/512) + DecoderRNN({args.lstm_layers}x512 "
+            f"LSTM, FC 256, 101 classes), {B} clips/GPU x 16 x 3 x 224 x 224, dropout {args.dropout}")
+    if args.model == "crnn":
+        cfg = types.SimpleNamespace(img_x=224, img_y=224, CNN_fc_hidden1=1024, CNN_fc_hidden2=768, CNN_embed_dim=512,
+                                    dropout_p=0.0, use_pretrained=False, RNN_hidden_layers=3, RNN_hidden_nodes=512,
+                                    RNN_FC_dim=256, num_classes=101)
+        return (O or M).CRNNModel(cfg), (B, 16, 3, 224, 224), (
+            f"CRNN training step: EncoderCNN(1024/768/512) + DecoderRNN(3x512), {B} clips/GPU x 16 x 3 x 224 x 224")
+    if args.model == "conv3d":
+        cfg = types.SimpleNamespace(dropout_p=0.5, num_classes=101)
+        return (O or M).Conv3DModel(cfg), (B, 1, 16, args.conv3d_size, args.conv3d_size), (
+            f"Conv3D training step: Conv3DModel, {B} clips/GPU x 1 x 16 x {args.conv3d_size} x {args.conv3d_size}, dropout 0.5")
+    if args.model == "swinrnn":
+        enc = (O or S).SwinTransformerEncoder(1024, 768, 0.0, 512)
+        dec = (O or M).DecoderRNN(512, args.lstm_layers, 512, 256, 0.0, 101)
+        return (O or M).SwinTransformerRNNModel(enc, dec), (B, 16, 3, 224, 224), (
+            f"swintransformer-RNN training step: Swin-T encoder (1024/768/512 head) + DecoderRNN({args.lstm_layers}x512), "
+            f"{B} clips/GPU x 16 x 3 x 224 x 224")
+    if args.model == "clusterswin":
+        enc = (O or S).ClusterSwinEncoder(embed_dim=96, k_tokens=8)
+        dec = (O or M).TCG_LSTM(96, 512, 2, 8, 4, 101, 0.1)
+        return (O or M).SwinTCGModel(enc, dec), (B, 16, 3, 224, 224), (
+            f"clusterSwin_TCGlstm training step: ClusterSwinEncoder(Swin-T, E=96, k=8) + TCG_LSTM(H=512, L=2, drop 0.1), "
+            f"{B} clips/GPU x 16 x 3 x 224 x 224")
+    raise SystemExit(f"unknown --model {args.model}")
+
+
 def model_config(args):
     return types.SimpleNamespace(CNN_fc_hidden1=1024, CNN_fc_hidden2=768, CNN_embed_dim=512, dropout_p=args.dropout,
                                  use_pretrained=False, RNN_hidden_layers=args.lstm_layers, RNN_hidden_nodes=512,
@@ -51,11 +88,11 @@ def cpu_baseline(args):
     from oracle import torch_oracle as O
     b = args.cpu_batch
     torch.manual_seed(0)
-    model = O.ResNetCRNNModel(model_config(args))
+    model, shape, _ = build_workload(args, None, None, oracle=True)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-4)
     crit = nn.CrossEntropyLoss()
     g = torch.Generator().manual_seed(1234)
-    x = torch.randn(b, 16, 3, 224, 224, generator=g)
+    x = torch.randn(b, *shape[1:], generator=g)
     y = torch.randint(0, 101, (b, 1), generator=g)
     O.train_step(model, x, y, crit, opt)  # warm-up
     t0 = time.perf_counter()
@@ -65,7 +102,7 @@ def cpu_baseline(args):
         n += 1
     dt = time.perf_counter() - t0
     return {"value": b * n / dt, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} training steps of {b} clips (16x3x224x224) after 1 warm-up, fp32, same architecture"}
+            "sample": f"{n} training steps of {b} clips {tuple(shape[1:])} after 1 warm-up, fp32, same architecture"}
 
 
 def main():
@@ -73,7 +110,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
+    ap.add_argument("--model", default="resnetcrnn", choices=["resnetcrnn", "crnn", "conv3d", "swinrnn", "clusterswin"])
+    ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default 32; 8 for the Swin models)")
+    ap.add_argument("--conv3d-size", type=int, default=112)
     ap.add_argument("--arch", default="resnet50", choices=["resnet50", "resnet101", "resnet152"])
     ap.add_argument("--lstm-layers", type=int, default=2)
     ap.add_argument("--dropout", type=float, default=0.3, help="configs/ResNetCRNN_train.yaml model.dropout")
@@ -83,8 +122,11 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--bucket-mb", type=int, default=32)
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 8 if args.model in ("swinrnn", "clusterswin") else 32
 
     from video_classification_amd import modules as M
+    from video_classification_amd import swin as S
     from video_classification_amd import ops
     from video_classification_amd import trainer as TR
 
@@ -98,14 +140,15 @@ def main():
 
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(0)
-    model = M.ResNetCRNNModel(model_config(args)).to(dev).set_compute_dtype(dt)
+    model, shape, workload = build_workload(args, M, S)
+    model = model.to(dev).set_compute_dtype(dt)
     opt = TR.get_optimizer(model, "adam", lr=1e-4, weight_decay=1e-4)
     TR.make_data_parallel(model, opt, bucket_mb=args.bucket_mb)
     crit = TR.FusedCrossEntropyLoss()
     ops.manual_seed(1234 + rank)
     g = torch.Generator().manual_seed(1234 + rank)
     B = args.batch
-    x = torch.randn(B, 16, 3, 224, 224, generator=g).to(dev)
+    x = torch.randn(*shape, generator=g).to(dev)
     y = torch.randint(0, 101, (B, 1), generator=g).to(dev)
     model.train()
 
@@ -171,11 +214,9 @@ def main():
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": f"ResNetCRNN training step: ResCNNEncoder({args.arch}, 1024/768/512) + DecoderRNN("
-                                   f"{args.lstm_layers}x512 LSTM, FC 256, 101 classes), {B} clips/GPU x 16 x 3 x 224 x 224, "
-                                   f"dropout {args.dropout}, fwd+CE+bwd+all-reduce+Adam",
+            "config": {"workload": workload + ", fwd+CE+bwd+all-reduce+Adam",
                        "global_batch": world * B, "frames_per_clip": 16, "parallelism": f"dp{world}"},
-            "loss": float(loss),
+            "loss": float(loss.detach()),
             "roofline": roof,
             "cpu_baseline": None,
         }

@@ -215,3 +215,28 @@ def test_resnet_crnn_vs_oracle(cuda, dt):
             assert G.max_rel(b.cpu(), br[k]) < tol_o, k
         else:
             assert int(b) == int(br[k]), k
+
+
+def test_lstm_interlayer_dropout_training(cuda):
+    """TCG_LSTM with drop=0.1 (configs/clusterSwin_TCGlstm.yaml) in training mode: nn.LSTM's inter-layer
+    dropout runs on the library's generator -- not parity-testable against torch's mask stream, so this
+    checks determinism under a fixed seed, that eval mode is unaffected, and finite gradients."""
+    from video_classification_amd import ops
+    from video_classification_amd.modules import TCG_LSTM
+    torch.manual_seed(0)
+    m = TCG_LSTM(24, 32, 2, 8, 4, 101, 0.1).to(cuda).set_compute_dtype(torch.float32)
+    g = torch.randn(2, 16, 24, device=cuda)
+    c = torch.randn(2, 16, 8, 24, device=cuda)
+    m.train()
+    ops.manual_seed(7)
+    o1 = m(g, c)
+    ops.manual_seed(7)
+    o2 = m(g, c)
+    o3 = m(g, c)
+    assert torch.equal(o1, o2) and not torch.equal(o1, o3)
+    o3.sum().backward()
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+    m.eval()
+    with torch.no_grad():
+        e1, e2 = m(g, c), m(g, c)
+    assert torch.equal(e1, e2)

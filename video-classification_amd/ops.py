@@ -417,7 +417,7 @@ class _LSTM(torch.autograd.Function):
     gradients of all steps are one GEMM over the whole sequence."""
 
     @staticmethod
-    def forward(ctx, x, H, layers, bidir, *params):
+    def forward(ctx, x, H, layers, bidir, drop_p, *params):
         _require_cuda(x, "lstm")
         x = x.contiguous()
         T, B, In = x.shape
@@ -427,6 +427,7 @@ class _LSTM(torch.autograd.Function):
         dev = x.device
         f32 = torch.float32
         saved = []
+        masks = {}
         inp = x
         st = L.stream()
         for l in range(layers):
@@ -457,6 +458,15 @@ class _LSTM(torch.autograd.Function):
                 saved.append((inp, c, act, wih_t, whh_t))
             saved.append(out)
             inp = out
+            if drop_p > 0.0 and l < layers - 1:  # nn.LSTM's inter-layer dropout (training mode only)
+                import ctypes
+                inp = torch.empty_like(out)
+                mask = torch.empty(out.shape, device=dev, dtype=torch.uint8)
+                _dropout_seed[0] = (_dropout_seed[0] * 6364136223846793005 + 1442695040888963407) & 0x7FFFFFFFFFFFFFFF
+                L.call("vc_dropout_fwd", code, L.ptr(out), L.ptr(inp), L.ptr(mask), L.i64(out.numel()), float(drop_p),
+                       ctypes.c_uint64(_dropout_seed[0]), st)
+                masks[l] = mask
+        ctx.masks, ctx.drop_p = masks, drop_p
         ctx.meta = (T, B, In, H, layers, dirs)
         ctx.params = params
         ctx.saved_objs = saved
@@ -530,15 +540,18 @@ class _LSTM(torch.autograd.Function):
                     L.call("vc_conv_dgrad", _lin_desc(T * B, Kin, 4 * H), code, L.ptr(dg), 0, L.ptr(wih_t),
                            L.ptr(dinp), 0, int(dt == torch.float32), int(d > 0), st)
             dlayer = dinp
-        return (dlayer, None, None, None) + (None,) * len(params)
+            if l > 0 and (l - 1) in ctx.masks:
+                dlayer = torch.empty_like(dinp)
+                L.call("vc_dropout_bwd", code, L.ptr(dinp), L.ptr(ctx.masks[l - 1]), L.ptr(dlayer), L.i64(dinp.numel()),
+                       float(ctx.drop_p), st)
+        return (dlayer, None, None, None, None) + (None,) * len(params)
 
 
 def lstm(x_tm, lstm_module):
-    """x_tm: [T,B,In] in the compute dtype; lstm_module: nn.LSTM holding the parameters (inter-layer
-    dropout must be 0 or the module in eval mode)."""
+    """x_tm: [T,B,In] in the compute dtype; lstm_module: nn.LSTM holding the parameters (its inter-layer
+    dropout is applied in training mode, with the library's own generator)."""
     m = lstm_module
-    if m.training and m.dropout > 0 and m.num_layers > 1:
-        raise RuntimeError("lstm: inter-layer dropout > 0 in training mode is not supported by the HIP path")
+    drop_p = float(m.dropout) if (m.training and m.num_layers > 1) else 0.0
     dirs = 2 if m.bidirectional else 1
     params = []
     for l in range(m.num_layers):
@@ -546,7 +559,7 @@ def lstm(x_tm, lstm_module):
             sfx = f"_l{l}" + ("_reverse" if d else "")
             params += [getattr(m, "weight_ih" + sfx), getattr(m, "weight_hh" + sfx), getattr(m, "bias_ih" + sfx),
                        getattr(m, "bias_hh" + sfx)]
-    return _LSTM.apply(x_tm, m.hidden_size, m.num_layers, m.bidirectional, *params)
+    return _LSTM.apply(x_tm, m.hidden_size, m.num_layers, m.bidirectional, drop_p, *params)
 
 
 # ----------------------------------------------------------------------------------------------
