@@ -118,6 +118,7 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.3, help="configs/ResNetCRNN_train.yaml model.dropout")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--bucket-mb", type=int, default=32)
@@ -152,7 +153,7 @@ def main():
     y = torch.randint(0, 101, (B, 1), generator=g).to(dev)
     model.train()
 
-    def step():
+    def eager_step():
         opt.zero_grad()
         out = model(x)
         loss = crit(out, y)
@@ -160,23 +161,49 @@ def main():
         opt.step()
         return loss
 
-    for _ in range(args.warmup):
-        step()
-
     def fence():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
 
-    ops.PROFILE = []
+    # Step executor: the whole step captured once into a hipGraph and replayed (default), or launched kernel by
+    # kernel from Python (--no-graph, and the fallback if capture is refused).  Same kernels, same work.
+    mode = "eager"
+    step = eager_step
+    if not args.no_graph:
+        try:
+            from video_classification_amd.graph import GraphedTrainStep
+            gstep = GraphedTrainStep(model, opt, crit, x, y, warmup=max(1, min(args.warmup, 3)))
+            step = lambda: gstep(gstep.x, gstep.y)  # noqa: E731  (inputs already resident in the static buffers)
+            mode = "hipgraph"
+        except Exception as exc:  # pragma: no cover - depends on the runtime
+            print(f"[bench] graph capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
+            torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step()
+
+    if mode == "eager":
+        ops.PROFILE = []
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     fence()
     elapsed = time.perf_counter() - t0
-    prof, ops.PROFILE = ops.PROFILE, None
+    prof_steps = args.steps
+    if mode == "eager":
+        prof, ops.PROFILE = ops.PROFILE, None
+        prof_where = "HIP events around every launch inside the timed region"
+    else:
+        # events cannot be recorded inside a replayed graph: time the same kernels in eager steps right after
+        prof_steps = 2
+        ops.PROFILE = []
+        for _ in range(prof_steps):
+            eager_step()
+        torch.cuda.synchronize()
+        prof, ops.PROFILE = ops.PROFILE, None
+        prof_where = f"HIP events around every launch in {prof_steps} eager steps run right after the timed region"
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -197,8 +224,9 @@ def main():
                 "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
                 "launches": n, "avg_launch_ms": tm / n * 1e3, "avg_launch_gflop": fl / n / 1e9,
                 "other_kernels": {k: {"achieved_tflops": v[0] / v[1] / 1e12, "launches": v[2],
-                                      "ms_per_step": v[1] / args.steps * 1e3}
-                                  for k, v in fam.items() if v[1] > 0}}
+                                      "ms_per_step": v[1] / prof_steps * 1e3}
+                                  for k, v in fam.items() if v[1] > 0},
+                "measured": prof_where}
 
     if rank == 0:
         line = {
@@ -215,7 +243,8 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": workload + ", fwd+CE+bwd+all-reduce+Adam",
-                       "global_batch": world * B, "frames_per_clip": 16, "parallelism": f"dp{world}"},
+                       "global_batch": world * B, "frames_per_clip": 16, "parallelism": f"dp{world}",
+                       "launch": mode},
             "loss": float(loss.detach()),
             "roofline": roof,
             "cpu_baseline": None,

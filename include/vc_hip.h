@@ -58,6 +58,10 @@ int vc_conv_fwd_naive_bf16(const int* desc, int mode, const void* src, const voi
                            void* out, int relu, int out_f32, vc_stream_t stream);
 int vc_pack_weight(int dtype, const float* w, void* w_fwd, void* w_t, int co, int ci, int taps, int ci_pad, int co_pad,
                    vc_stream_t stream);
+/* data-gradient pack [taps*ci_pad][co_pad] for a convolution whose kernel covers its whole input, i.e. a Linear
+ * layer over the flattened channels-last map (EncoderCNN.fc1 after x.view(B,-1), model_components.py:131-134) */
+int vc_pack_weight_flat_t(int dtype, const float* w, void* w_t, int co, int ci, int taps, int ci_pad, int co_pad,
+                          vc_stream_t stream);
 int vc_unpack_wgrad(const float* dw_packed, float* dw, int co, int ci, int taps, int ci_pad, int accumulate,
                     vc_stream_t stream);
 
@@ -107,13 +111,14 @@ int vc_cast(int src_dtype, int dst_dtype, const void* a, void* out, int64_t n, v
 /* bias gradients: out[c] += sum_m a[m][c] */
 int vc_colsum(int dtype, const void* a, float* out, int M, int C, int lda, vc_stream_t stream);
 /* F.dropout (model_components.py:136,184,228,297,302), nn.Dropout (Conv3D :95,98; TCG_LSTM :488) */
+/* seed_dev (nullable): device counter folded into the seed at execution time (new masks on graph replays) */
 int vc_dropout_fwd(int dtype, const void* x, void* out, uint8_t* mask, int64_t n, float p, uint64_t seed,
-                   vc_stream_t stream);
+                   const int64_t* seed_dev, vc_stream_t stream);
 int vc_dropout_bwd(int dtype, const void* dy, const uint8_t* mask, void* dx, int64_t n, float p, vc_stream_t stream);
 
 /* timm's DropPath (stochastic depth) inside the Swin blocks; backward applies the same call to the gradient */
 int vc_drop_path(int dtype, const void* x, void* out, int64_t n, int64_t elems_per_sample, float p, uint64_t seed,
-                 vc_stream_t stream);
+                 const int64_t* seed_dev, vc_stream_t stream);
 
 /* ---- Swin-T window attention / patch merging (timm swin_tiny_patch4_window7_224 behind
  * model_components.py:254, 412).  qkv [B*H*W][3C] in token order; window partition, cyclic shift, relative
@@ -154,7 +159,11 @@ int vc_ce_fwd_bwd(int grad_dtype, const float* logits, int ld, const int64_t* ta
 /* optim.Adam (L2-coupled) / AdamW / SGD(momentum) (training_utils.py:324-329) over one flat fp32 buffer.
  * mode 0 Adam, 1 AdamW, 2 SGD (b1 = momentum).  grad_scale folds the 1/world of the all-reduce. */
 int vc_optim_step(int mode, float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
-                  float eps, float wd, int step, float grad_scale, vc_stream_t stream);
+                  float eps, float wd, int step, float grad_scale, const float* lr_dev, const int64_t* step_dev,
+                  vc_stream_t stream);
+/* *counter += inc on the stream: the device-resident step counter that lr_dev/step_dev/seed_dev users read, so
+ * that a hipGraph of the whole training step replays with current values */
+int vc_counter_add(int64_t* counter, int64_t inc, vc_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -51,7 +51,7 @@ def test_version_and_error_reporting(lib):
     assert rc == -1
     assert b"output extent" in lib.vc_last_error()
     rc = lib.vc_optim_step(7, None, None, None, None, ctypes.c_int64(0), ctypes.c_float(0), ctypes.c_float(0),
-                           ctypes.c_float(0), ctypes.c_float(0), ctypes.c_float(0), 1, ctypes.c_float(1), None)
+                           ctypes.c_float(0), ctypes.c_float(0), ctypes.c_float(0), 1, ctypes.c_float(1), None, None, None)
     assert rc == -4
 
 

@@ -207,7 +207,8 @@ def test_resnet_crnn_vs_oracle(cuda, dt):
     grefs = {k: p.grad for k, p in ref.named_parameters()}
     # 19 BatchNorm layers whose statistics come from 6 frames amplify rounding (measured 6e-3 on the stem
     # weight in fp32): 3x the per-model bound
-    G.check_grads(dict(mine.named_parameters()), grefs, 3 * tol_g if dt == torch.bfloat16 else 1e-2,
+    # (fp32: L2 bound 2e-2; single elements of the first layers reach 4.5e-2 of the tensor's maximum)
+    G.check_grads(dict(mine.named_parameters()), grefs, 3 * tol_g if dt == torch.bfloat16 else 2e-2,
                   cancelled=["encoder.fc1.bias", "encoder.fc2.bias"])
     br = dict(ref.named_buffers())
     for k, b in mine.named_buffers():
@@ -240,3 +241,45 @@ def test_lstm_interlayer_dropout_training(cuda):
     with torch.no_grad():
         e1, e2 = m(g, c), m(g, c)
     assert torch.equal(e1, e2)
+
+
+def test_graphed_train_step_matches_eager(cuda):
+    """The hipGraph replay of the step (zero-grad + fwd + CE + bwd + fused Adam) must produce the weights the
+    eager step produces; Adam's bias correction and learning rate are read from device memory at replay time."""
+    from video_classification_amd import trainer as TR
+    from video_classification_amd.graph import GraphedTrainStep
+    from video_classification_amd.modules import CRNNModel
+    d = G.load("crnn_tiny_step")
+    x = torch.from_numpy(d["in/x"]).to(cuda)
+    y = torch.from_numpy(d["in/y"]).to(cuda)
+    results = []
+    for graphed in (False, True):
+        model = CRNNModel(G.tiny_crnn_config())
+        model.load_state_dict(G.group(d, "p"), strict=True)
+        model.to(cuda).set_compute_dtype(torch.float32)
+        opt = TR.get_optimizer(model, "adam", lr=1e-3, weight_decay=1e-4)
+        crit = TR.FusedCrossEntropyLoss()
+        model.train()
+        losses = []
+        if graphed:
+            gs = GraphedTrainStep(model, opt, crit, x, y, warmup=2)  # 2 real steps
+            for k in range(3):
+                if k == 2:
+                    opt.param_groups[0]["lr"] = 5e-4  # a scheduler step between replays
+                losses.append(gs(x, y).item())
+        else:
+            for k in range(5):
+                if k == 4:
+                    opt.param_groups[0]["lr"] = 5e-4
+                opt.zero_grad()
+                loss = crit(model(x), y)
+                loss.backward()
+                opt.step()
+                if k >= 2:
+                    losses.append(loss.item())
+        assert opt.steps == 5
+        results.append((losses, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}))
+    (le, se), (lg, sg) = results
+    assert max(abs(a - b) for a, b in zip(le, lg)) < 1e-4
+    for k in se:
+        assert (se[k].double() - sg[k].double()).abs().max().item() < 1e-5, k

@@ -22,7 +22,9 @@ __device__ __forceinline__ uint32_t mix_u32(uint64_t seed, uint64_t idx) {
 
 template <typename T>
 __global__ void dropout_fwd_kernel(const T* __restrict__ x, T* __restrict__ out, uint8_t* __restrict__ mask,
-                                   int64_t n, uint32_t thresh, float scale, uint64_t seed) {
+                                   int64_t n, uint32_t thresh, float scale, uint64_t seed,
+                                   const int64_t* __restrict__ seed_dev) {
+  if (seed_dev) seed += (uint64_t)*seed_dev * 0xD1B54A32D192ED03ull;  // advances with the device step counter
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const bool keep = mix_u32(seed, (uint64_t)i) >= thresh;
     mask[i] = keep;
@@ -41,7 +43,8 @@ __global__ void dropout_bwd_kernel(const T* __restrict__ dy, const uint8_t* __re
 // decision is a pure function of (seed, sample), so backward re-applies the same kernel to the gradient
 template <typename T>
 __global__ void drop_path_kernel(const T* __restrict__ x, T* __restrict__ out, int64_t n8, int64_t chunks_per_sample,
-                                 uint32_t thresh, float scale, uint64_t seed) {
+                                 uint32_t thresh, float scale, uint64_t seed, const int64_t* __restrict__ seed_dev) {
+  if (seed_dev) seed += (uint64_t)*seed_dev * 0xD1B54A32D192ED03ull;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
     const bool keep = mix_u32(seed, (uint64_t)(i / chunks_per_sample)) >= thresh;
     F8 v = load8(x + i * 8);
@@ -283,14 +286,16 @@ __global__ void tcg_inputs_bwd_kernel(const T* __restrict__ dshort, const T* __r
 
 extern "C" {
 
+// seed_dev (nullable): a device counter folded into the seed at execution time, so that a captured graph draws a
+// new mask on every replay
 int vc_dropout_fwd(int dtype, const void* x, void* out, uint8_t* mask, int64_t n, float p, uint64_t seed,
-                   hipStream_t stream) {
+                   const int64_t* seed_dev, hipStream_t stream) {
   VC_CHECK_ARG(x && out && mask && n > 0 && p >= 0.f && p < 1.f, "vc_dropout_fwd: bad argument");
   const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
   const float scale = 1.f / (1.f - p);
   DISPATCH_T(dtype, "vc_dropout_fwd",
              hipLaunchKernelGGL((dropout_fwd_kernel<T>), dim3(ew_grid(n)), dim3(NTHR), 0, stream, (const T*)x, (T*)out,
-                                mask, n, thresh, scale, seed);)
+                                mask, n, thresh, scale, seed, seed_dev);)
   VC_LAUNCH_CHECK("vc_dropout_fwd");
   return VC_OK;
 }
@@ -306,7 +311,7 @@ int vc_dropout_bwd(int dtype, const void* dy, const uint8_t* mask, void* dx, int
 }
 
 int vc_drop_path(int dtype, const void* x, void* out, int64_t n, int64_t elems_per_sample, float p, uint64_t seed,
-                 hipStream_t stream) {
+                 const int64_t* seed_dev, hipStream_t stream) {
   VC_CHECK_ARG(x && out && n > 0 && p >= 0.f && p < 1.f, "vc_drop_path: bad argument");
   VC_CHECK_SHAPE(n % 8 == 0 && elems_per_sample % 8 == 0 && elems_per_sample > 0 && n % elems_per_sample == 0,
                  "vc_drop_path: sizes must be multiples of 8 and of the per-sample size");
@@ -314,7 +319,7 @@ int vc_drop_path(int dtype, const void* x, void* out, int64_t n, int64_t elems_p
   const float scale = 1.f / (1.f - p);
   DISPATCH_T(dtype, "vc_drop_path",
              hipLaunchKernelGGL((drop_path_kernel<T>), dim3(ew_grid(n / 8)), dim3(NTHR), 0, stream, (const T*)x,
-                                (T*)out, n / 8, elems_per_sample / 8, thresh, scale, seed);)
+                                (T*)out, n / 8, elems_per_sample / 8, thresh, scale, seed, seed_dev);)
   VC_LAUNCH_CHECK("vc_drop_path");
   return VC_OK;
 }

@@ -554,6 +554,19 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
   }
 }
 
+// data-gradient pack of a convolution whose kernel covers its whole input (a Linear layer over the
+// flattened channels-last map): wt[(tap*Cip + c)][Cop]
+template <typename T>
+__global__ void pack_weight_flat_t_kernel(const float* __restrict__ w, T* __restrict__ wt, int Co, int Ci, int taps,
+                                          int Cip, int Cop) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)taps * Cip * Cop) return;
+  const int co = (int)(idx % Cop);
+  const int c = (int)((idx / Cop) % Cip);
+  const int tap = (int)(idx / ((int64_t)Cop * Cip));
+  wt[idx] = from_f32<T>((co < Co && c < Ci) ? w[((size_t)co * Ci + c) * taps + tap] : 0.f);
+}
+
 // packed fp32 gradient [Co][taps][Cip] -> torch layout [Co][Ci][taps] (accumulating or not)
 __global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Co, int Ci, int taps,
                                     int Cip, int accumulate) {
@@ -746,6 +759,25 @@ int vc_pack_weight(int dtype, const float* w, void* w_fwd, void* w_t, int co, in
     return VC_ERR_DTYPE;
   }
   VC_LAUNCH_CHECK("vc_pack_weight");
+  return VC_OK;
+}
+
+int vc_pack_weight_flat_t(int dtype, const float* w, void* w_t, int co, int ci, int taps, int ci_pad, int co_pad,
+                          hipStream_t stream) {
+  VC_CHECK_ARG(w && w_t, "vc_pack_weight_flat_t: null pointer");
+  VC_CHECK_SHAPE(co > 0 && ci > 0 && taps > 0 && ci_pad >= ci && co_pad >= co, "vc_pack_weight_flat_t: bad shape");
+  const int64_t total = (int64_t)taps * ci_pad * co_pad;
+  if (dtype == VC_BF16)
+    hipLaunchKernelGGL((pack_weight_flat_t_kernel<bf16>), dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, stream,
+                       w, (bf16*)w_t, co, ci, taps, ci_pad, co_pad);
+  else if (dtype == VC_F32)
+    hipLaunchKernelGGL((pack_weight_flat_t_kernel<float>), dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0,
+                       stream, w, (float*)w_t, co, ci, taps, ci_pad, co_pad);
+  else {
+    vc_set_error("vc_pack_weight_flat_t: unsupported dtype %d", dtype);
+    return VC_ERR_DTYPE;
+  }
+  VC_LAUNCH_CHECK("vc_pack_weight_flat_t");
   return VC_OK;
 }
 

@@ -211,7 +211,7 @@ __global__ void cast_kernel(const TI* __restrict__ a, TO* __restrict__ out, int6
     out[i] = from_f32<TO>(to_f32(a[i]));
 }
 
-// column sums of [M][C] (bias gradients): out[c] (+)= sum_m a[m][c]
+// column sums of [M][C] (bias gradients): out[c] += sum_m a[m][c]
 template <typename T>
 __global__ void colsum_kernel(const T* __restrict__ a, float* __restrict__ out, int M, int C, int lda,
                               int rows_per_block) {
@@ -221,6 +221,48 @@ __global__ void colsum_kernel(const T* __restrict__ a, float* __restrict__ out, 
   float acc = 0.f;
   for (int r = r0; r < r1; ++r) acc += to_f32(a[(size_t)r * lda + c]);
   atomicAdd(out + c, acc);
+}
+
+// vectorised variant for dense rows with C % 8 == 0: 8 channels per lane, the block's row lanes are
+// reduced through LDS, one atomic per channel per block
+template <typename T>
+__global__ void colsum_vec_kernel(const T* __restrict__ a, float* __restrict__ out, int M, int C, int Cvalid,
+                                  int rows_per_block) {
+  __shared__ float red[NTHR][8];
+  const int C8 = C >> 3;
+  const int lanesC = C8 < NTHR ? C8 : NTHR;
+  const int RL = NTHR / lanesC;
+  const int tid = threadIdx.x;
+  const int cl = tid % lanesC, rl = tid / lanesC;
+  const int r_begin = blockIdx.x * rows_per_block;
+  const int r_end = min(M, r_begin + rows_per_block);
+  for (int cc0 = 0; cc0 < C8; cc0 += lanesC) {
+    const int cc = cc0 + cl;
+    const bool cvalid = cc < C8;
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    if (rl < RL && cvalid) {
+      for (int r = r_begin + rl; r < r_end; r += RL) {
+        const F8 v = load8(a + (size_t)r * C + cc * 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += v.v[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[tid][i] = acc[i];
+    __syncthreads();
+    if (rl == 0 && cvalid) {
+      for (int k = 1; k < RL; ++k) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += red[k * lanesC + cl][i];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (cc * 8 + i < Cvalid) atomicAdd(out + cc * 8 + i, acc[i]);
+    }
+    __syncthreads();
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -337,7 +379,15 @@ __global__ void ce_kernel(const float* __restrict__ logits, int ld, const int64_
 // ---------------------------------------------------------------------------
 __global__ void optim_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                              float* __restrict__ v, int64_t n, int mode, float lr, float b1, float b2, float eps,
-                             float wd, float bc1, float bc2_sqrt, float grad_scale, int first_step) {
+                             float wd, int step, float grad_scale, const float* __restrict__ lr_dev,
+                             const int64_t* __restrict__ step_dev) {
+  // hyper-parameters that change between steps may live in device memory so that a captured graph of the
+  // training step replays with the current values
+  if (lr_dev) lr = *lr_dev;
+  if (step_dev) step = (int)*step_dev;
+  const float bc1 = 1.f - (float)pow((double)b1, (double)step);
+  const float bc2_sqrt = sqrtf(1.f - (float)pow((double)b2, (double)step));
+  const int first_step = step <= 1;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     float pv = p[i];
     float gv = g[i] * grad_scale;
@@ -357,6 +407,10 @@ __global__ void optim_kernel(float* __restrict__ p, const float* __restrict__ g,
     const float denom = sqrtf(vv) / bc2_sqrt + eps;
     p[i] = pv - (lr / bc1) * (mv / denom);
   }
+}
+
+__global__ void counter_add_kernel(int64_t* c, int64_t inc) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *c += inc;
 }
 
 }  // namespace
@@ -461,12 +515,21 @@ int vc_cast(int src_dtype, int dst_dtype, const void* a, void* out, int64_t n, h
 // out[c] += sum over rows (caller zeroes or keeps a running gradient)
 int vc_colsum(int dtype, const void* a, float* out, int M, int C, int lda, hipStream_t stream) {
   VC_CHECK_ARG(a && out && M > 0 && C > 0 && lda >= C, "vc_colsum: bad argument");
-  int rows_per_block = 64;
-  while (ceil_div(M, rows_per_block) > 512) rows_per_block *= 2;
-  dim3 grid(ceil_div(C, 64), ceil_div(M, rows_per_block));
-  DISPATCH_T(dtype, "vc_colsum",
-             hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(64), 0, stream, (const T*)a, out, M, C, lda,
-                                rows_per_block);)
+  if (lda % 8 == 0) {
+    // rows are dense with `lda` (a multiple of 8) channels, of which the first C are summed
+    int rows_per_block = 256;
+    while (ceil_div(M, rows_per_block) > 1024) rows_per_block *= 2;
+    DISPATCH_T(dtype, "vc_colsum",
+               hipLaunchKernelGGL((colsum_vec_kernel<T>), dim3(ceil_div(M, rows_per_block)), dim3(NTHR), 0, stream,
+                                  (const T*)a, out, M, lda, C, rows_per_block);)
+  } else {
+    int rows_per_block = 64;
+    while (ceil_div(M, rows_per_block) > 512) rows_per_block *= 2;
+    dim3 grid(ceil_div(C, 64), ceil_div(M, rows_per_block));
+    DISPATCH_T(dtype, "vc_colsum",
+               hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(64), 0, stream, (const T*)a, out, M, C, lda,
+                                  rows_per_block);)
+  }
   VC_LAUNCH_CHECK("vc_colsum");
   return VC_OK;
 }
@@ -511,16 +574,24 @@ int vc_ce_fwd_bwd(int grad_dtype, const float* logits, int ld, const int64_t* ta
   return VC_OK;
 }
 
+// lr_dev / step_dev (nullable) override lr / step with values read from device memory at execution time
 int vc_optim_step(int mode, float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
-                  float eps, float wd, int step, float grad_scale, hipStream_t stream) {
-  VC_CHECK_ARG(p && g && m && n > 0 && step >= 1, "vc_optim_step: bad argument");
+                  float eps, float wd, int step, float grad_scale, const float* lr_dev, const int64_t* step_dev,
+                  hipStream_t stream) {
+  VC_CHECK_ARG(p && g && m && n > 0 && (step >= 1 || step_dev), "vc_optim_step: bad argument");
   VC_CHECK_ARG(mode == 2 || v, "vc_optim_step: second-moment buffer missing");
   VC_CHECK_ARG(mode >= 0 && mode <= 2, "vc_optim_step: unknown mode %d", mode);
-  const double bc1 = 1.0 - pow((double)b1, (double)step);
-  const double bc2 = 1.0 - pow((double)b2, (double)step);
   hipLaunchKernelGGL(optim_kernel, dim3(ew_grid(n)), dim3(NTHR), 0, stream, p, g, m, v, n, mode, lr, b1, b2, eps, wd,
-                     (float)bc1, (float)sqrt(bc2), grad_scale, step == 1);
+                     step, grad_scale, lr_dev, step_dev);
   VC_LAUNCH_CHECK("vc_optim_step");
+  return VC_OK;
+}
+
+// *counter += inc on the stream (device-resident step counter of the optimizer / dropout generator)
+int vc_counter_add(int64_t* counter, int64_t inc, hipStream_t stream) {
+  VC_CHECK_ARG(counter, "vc_counter_add: null pointer");
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, stream, counter, inc);
+  VC_LAUNCH_CHECK("vc_counter_add");
   return VC_OK;
 }
 

@@ -337,6 +337,433 @@ __global__ void patch_merge_kernel(const T* __restrict__ in, T* __restrict__ out
   }
 }
 
+// ============================================================================================
+// MFMA path (bf16).  One wave per (window, head); the 49 tokens are padded to 64 (4 MFMA tiles).
+//
+// The scores are produced TRANSPOSED, S^T[j][i] = sum_e K[j][e] Q[i][e] = mfma(A = K rows, B = Q rows), so that
+// a lane holds one query column i = 16*ti + (lane & 15) and its keys j = 16*tj + 4*(lane >> 4) + r in registers:
+// the softmax over j is 16 in-lane values plus two cross-lane steps (xor 16, 32), and the accumulator tiles are
+// directly the B operand of the next product, which contracts over j:  O^T[e][i] = sum_j V^T[e][j] P^T[j][i].
+// Its A operand V^T is read from the row-major LDS tile V[j][e] with the transposing read ds_read_b64_tr_b16,
+// taking for k-step s the rows j = 16*(2s + (jj >> 2)) + 4*(lane >> 4) + (jj & 3), i.e. the same permuted k
+// order in which the accumulator registers enumerate j.
+// The backward pass needs P and dS in both orientations (contractions over j for dQ, over i for dK / dV); both
+// are recomputed with MFMAs (S^T and S, dP^T and dP: 4 x 16 MFMAs) rather than transposed through LDS.
+// ============================================================================================
+constexpr int AW = 4;             // waves (units) per block
+constexpr int TS = 64 * HD;       // elements of one [64 tokens][32] bf16 tile
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
+
+__device__ __forceinline__ bf16x8 frag_rows(const bf16* tile, int t, int lane) {
+  // A/B fragment of a row-major [64][32] tile for token tile t: row 16t + (lane & 15), k = 8*(lane >> 4) ..
+  return *reinterpret_cast<const bf16x8*>(tile + (16 * t + (lane & 15)) * HD + 8 * (lane >> 4));
+}
+
+__device__ __forceinline__ bf16x8 frag_tr(const bf16* tile, int s, int te, int lane) {
+  // A fragment of tile^T: row e = 16*te + (lane & 15), k-step s in the accumulator's permuted token order
+  const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  const bf16* p0 = tile + (16 * (2 * s) + 4 * g + q) * HD + 16 * te + 4 * pp;
+  const bf16* p1 = p0 + 16 * HD;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)p0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)p1);
+  union {
+    struct {
+      s16x4 a, b;
+    } s;
+    bf16x8 v;
+  } u;
+  u.s.a = lo;
+  u.s.b = hi;
+  return u.v;
+}
+
+// B fragment for k-step s from accumulator tiles t[2s], t[2s+1] (4 values each)
+__device__ __forceinline__ bf16x8 frag_from_acc(const f32x4& a, const f32x4& b) {
+  bf16x8 f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    f[r] = (bf16)a[r];
+    f[4 + r] = (bf16)b[r];
+  }
+  return f;
+}
+
+struct UnitCtx {
+  int b, wh, ww, head;
+  bool valid;
+};
+
+// stage the [64][32] tile of `which` (0 q, 1 k, 2 v of qkv; or dout when src_is_out) for this unit: lane <-> token
+__device__ __forceinline__ void stage_tile(bf16* tile, const bf16* src, size_t row_elems, int col0, int tok, bool tvalid,
+                                           int lane) {
+  bf16x8 v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  if (tvalid) {
+    const bf16* row = src + (size_t)tok * row_elems + col0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const bf16x8*>(row + 8 * k);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) *reinterpret_cast<bf16x8*>(tile + lane * HD + 8 * k) = v[k];
+}
+
+// scale * S + bias + mask for the accumulator tile whose element r is (row rr0 + r, col cc) in (j, i) or (i, j)
+// orientation; TRANSPOSED = true: rows are keys j, cols are queries i.
+template <bool TRANSPOSED>
+__device__ __forceinline__ float score_of(float acc, int row, int col, int N, int ws, const float* sBias,
+                                          const int* sReg, const int* sRC, int shift, float scale) {
+  const int i = TRANSPOSED ? col : row, j = TRANSPOSED ? row : col;
+  if (j >= N) return -INFINITY;
+  const int ic = i < N ? i : N - 1;
+  // sRC[t] = (t / ws) * (2ws-1) + (t % ws): the bias index is sRC[i] - sRC[j] + (ws-1)*(2ws-1) + (ws-1)
+  float s = acc * scale + sBias[sRC[ic] - sRC[j] + (ws - 1) * (2 * ws)];
+  if (shift && sReg[ic] != sReg[j]) s -= 100.f;
+  return s;
+}
+
+__global__ __launch_bounds__(64 * AW) void window_attn_fwd_mfma_kernel(SwinGeom g, const bf16* __restrict__ qkv,
+                                                                        const float* __restrict__ bias_table,
+                                                                        bf16* __restrict__ out, float scale,
+                                                                        int units_total) {
+  __shared__ __attribute__((aligned(16))) bf16 sT[AW][3][TS];   // q, k, v tiles per wave
+  __shared__ float sBias[AW][176];
+  __shared__ int sReg[AW][64];
+  __shared__ int sTok[AW][64];
+  __shared__ int sRC[64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int N = g.ws * g.ws;
+  if (threadIdx.x < 64) sRC[threadIdx.x] = (threadIdx.x / g.ws) * (2 * g.ws - 1) + (threadIdx.x % g.ws);
+  int unit = blockIdx.x * AW + wave;
+  const bool uvalid = unit < units_total;
+  if (!uvalid) unit = units_total - 1;
+  const int head = unit % g.heads;
+  int u = unit / g.heads;
+  const int ww = u % g.nww;
+  u /= g.nww;
+  const int wh = u % g.nwh;
+  const int b = u / g.nwh;
+
+  int tok = 0, reg = 0;
+  const bool tvalid = lane < N;
+  if (tvalid) {
+    int ph, pw;
+    tok = token_of(g, b, wh, ww, lane, ph, pw);
+    reg = region_of(ph, g.H, g.ws, g.shift) * 3 + region_of(pw, g.W, g.ws, g.shift);
+  }
+  sReg[wave][lane] = reg;
+  sTok[wave][lane] = tvalid ? tok : -1;
+  const int nb = (2 * g.ws - 1) * (2 * g.ws - 1);
+  for (int k = lane; k < nb; k += 64) sBias[wave][k] = bias_table[k * g.heads + head];
+#pragma unroll
+  for (int w3 = 0; w3 < 3; ++w3) stage_tile(sT[wave][w3], qkv, (size_t)3 * g.C, w3 * g.C + head * HD, tok, tvalid, lane);
+  __syncthreads();
+
+  const bf16* tQ = sT[wave][0];
+  const bf16* tK = sT[wave][1];
+  const bf16* tV = sT[wave][2];
+  bf16x8 qf[4], kf[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    qf[t] = frag_rows(tQ, t, lane);
+    kf[t] = frag_rows(tK, t, lane);
+  }
+  f32x4 st[4][4];  // S^T[tj][ti]
+#pragma unroll
+  for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+      st[tj][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[tj], qf[ti], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+
+  const int gq = lane >> 4;
+  float inv_sum[4];
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti) {
+    const int i = 16 * ti + (lane & 15);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float s = score_of<true>(st[tj][ti][r], 16 * tj + 4 * gq + r, i, N, g.ws, sBias[wave], sReg[wave], sRC,
+                                       g.shift, scale);
+        st[tj][ti][r] = s;
+        mx = fmaxf(mx, s);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __expf(st[tj][ti][r] - mx);
+        st[tj][ti][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    inv_sum[ti] = 1.f / sum;
+  }
+
+  f32x4 ot[2][4];  // O^T[te][ti]
+#pragma unroll
+  for (int te = 0; te < 2; ++te)
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) ot[te][ti] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    bf16x8 vt[2], pf[4];
+#pragma unroll
+    for (int te = 0; te < 2; ++te) vt[te] = frag_tr(tV, s, te, lane);
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) pf[ti] = frag_from_acc(st[2 * s][ti], st[2 * s + 1][ti]);
+#pragma unroll
+    for (int te = 0; te < 2; ++te)
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti)
+        ot[te][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt[te], pf[ti], ot[te][ti], 0, 0, 0);
+  }
+  if (uvalid) {
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {
+      const int i = 16 * ti + (lane & 15);
+      if (i >= N) continue;
+      const int tk = sTok[wave][i];
+      bf16* orow = out + (size_t)tk * g.C + head * HD;
+#pragma unroll
+      for (int te = 0; te < 2; ++te) {
+        bf16x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (bf16)(ot[te][ti][r] * inv_sum[ti]);
+        *reinterpret_cast<bf16x4*>(orow + 16 * te + 4 * gq) = v;
+      }
+    }
+  }
+}
+
+// grid = (window chunks, heads); each wave walks `wpw` windows of one head and accumulates the bias gradient of
+// its windows in a per-wave LDS matrix [i][j] (every (i, j) is owned by exactly one lane register, so the LDS
+// adds never collide), flushed to the table with one atomic per (i, j) at the end.
+__global__ __launch_bounds__(64 * AW, 1) void window_attn_bwd_mfma_kernel(SwinGeom g, const bf16* __restrict__ qkv,
+                                                                           const bf16* __restrict__ dout,
+                                                                           const float* __restrict__ bias_table,
+                                                                           bf16* __restrict__ dqkv,
+                                                                           float* __restrict__ dbias_table,
+                                                                           float scale, int windows_total, int wpw) {
+  __shared__ __attribute__((aligned(16))) bf16 sT[AW][4][TS];   // q, k, v, dO tiles per wave
+  __shared__ float sDB[AW][MAXN * MAXN];
+  __shared__ float sBias[AW][176];
+  __shared__ float sBin[176];
+  __shared__ int sReg[AW][64];
+  __shared__ int sTok[AW][64];
+  __shared__ int sRC[64];
+  __shared__ float sMax[AW][64], sInv[AW][64], sDot[AW][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int gq = lane >> 4;
+  const int N = g.ws * g.ws;
+  const int head = blockIdx.y;
+  const int nb = (2 * g.ws - 1) * (2 * g.ws - 1);
+  if (threadIdx.x < 64) sRC[threadIdx.x] = (threadIdx.x / g.ws) * (2 * g.ws - 1) + (threadIdx.x % g.ws);
+  if (threadIdx.x < 176) sBin[threadIdx.x] = 0.f;
+  for (int k = lane; k < nb; k += 64) sBias[wave][k] = bias_table[k * g.heads + head];
+  for (int k = lane; k < MAXN * MAXN; k += 64) sDB[wave][k] = 0.f;
+
+  const int w_first = (blockIdx.x * AW + wave) * wpw;
+  for (int it = 0; it < wpw; ++it) {
+    int win = w_first + it;
+    const bool uvalid = win < windows_total;
+    if (!uvalid) win = windows_total - 1;
+    int u = win;
+    const int ww = u % g.nww;
+    u /= g.nww;
+    const int wh = u % g.nwh;
+    const int b = u / g.nwh;
+    int tok = 0, reg = 0;
+    const bool tvalid = lane < N;
+    if (tvalid) {
+      int ph, pw;
+      tok = token_of(g, b, wh, ww, lane, ph, pw);
+      reg = region_of(ph, g.H, g.ws, g.shift) * 3 + region_of(pw, g.W, g.ws, g.shift);
+    }
+    __syncthreads();  // every wave has finished reading the previous window's LDS
+    sReg[wave][lane] = reg;
+    sTok[wave][lane] = tvalid ? tok : -1;
+#pragma unroll
+    for (int w3 = 0; w3 < 3; ++w3)
+      stage_tile(sT[wave][w3], qkv, (size_t)3 * g.C, w3 * g.C + head * HD, tok, tvalid, lane);
+    stage_tile(sT[wave][3], dout, (size_t)g.C, head * HD, tok, tvalid, lane);
+    __syncthreads();
+    const bf16* tQ = sT[wave][0];
+    const bf16* tK = sT[wave][1];
+    const bf16* tV = sT[wave][2];
+    const bf16* tD = sT[wave][3];
+
+    // ---- orientation 1: rows j, columns i (lane <-> query i); one column tile ti at a time ------------
+    f32x4 dq[2][4];
+#pragma unroll
+    for (int te = 0; te < 2; ++te)
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) dq[te][ti] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {
+      const int i = 16 * ti + (lane & 15);
+      const bf16x8 qf = frag_rows(tQ, ti, lane), df = frag_rows(tD, ti, lane);
+      f32x4 st[4], dp[4];
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj) {
+        st[tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(tK, tj, lane), qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        dp[tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(tV, tj, lane), df, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float sc = score_of<true>(st[tj][r], 16 * tj + 4 * gq + r, i, N, g.ws, sBias[wave], sReg[wave], sRC,
+                                          g.shift, scale);
+          st[tj][r] = sc;
+          mx = fmaxf(mx, sc);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __expf(st[tj][r] - mx);
+          st[tj][r] = e;
+          sum += e;
+        }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv = 1.f / sum;
+      float dot = 0.f;
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          st[tj][r] *= inv;  // P^T
+          dot = fmaf(st[tj][r], dp[tj][r], dot);
+        }
+      dot += __shfl_xor(dot, 16, 64);
+      dot += __shfl_xor(dot, 32, 64);
+      if (gq == 0) {
+        sMax[wave][i] = mx;
+        sInv[wave][i] = inv;
+        sDot[wave][i] = dot;
+      }
+      const bool ivalid = (i < N) && uvalid;
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float ds = st[tj][r] * (dp[tj][r] - dot);  // dS^T (zero where P is zero: j >= N)
+          st[tj][r] = ds;
+          const int j = 16 * tj + 4 * gq + r;
+          if (ivalid && j < N) atomicAdd(&sDB[wave][i * MAXN + j], ds);
+        }
+      // dQ^T[e][i] += sum_j K^T[e][j] dS^T[j][i]
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 sf = frag_from_acc(st[2 * s2], st[2 * s2 + 1]);
+#pragma unroll
+        for (int te = 0; te < 2; ++te)
+          dq[te][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(tK, s2, te, lane), sf, dq[te][ti], 0, 0, 0);
+      }
+    }
+    if (uvalid) {
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) {
+        const int i = 16 * ti + (lane & 15);
+        if (i >= N) continue;
+        bf16* drow = dqkv + (size_t)sTok[wave][i] * 3 * g.C + head * HD;
+#pragma unroll
+        for (int te = 0; te < 2; ++te) {
+          bf16x4 v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = (bf16)(dq[te][ti][r] * scale);
+          *reinterpret_cast<bf16x4*>(drow + 16 * te + 4 * gq) = v;
+        }
+      }
+    }
+    __syncthreads();  // sMax / sInv / sDot written by the lanes that own i are visible to every lane
+    // ---- orientation 2: rows i, columns j (lane <-> key j); two row tiles (one k-step) at a time ---------
+    f32x4 dv[2][4], dk[2][4];
+#pragma unroll
+    for (int te = 0; te < 2; ++te)
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj) dv[te][tj] = dk[te][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      f32x4 st[2][4], dp[2][4];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int ti = 2 * s2 + h;
+        const bf16x8 qf = frag_rows(tQ, ti, lane), df = frag_rows(tD, ti, lane);
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) {
+          st[h][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, frag_rows(tK, tj, lane), f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          dp[h][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, frag_rows(tV, tj, lane), f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * ti + 4 * gq + r;
+          const float mx = sMax[wave][i], inv = sInv[wave][i], dot = sDot[wave][i];
+#pragma unroll
+          for (int tj = 0; tj < 4; ++tj) {
+            const int j = 16 * tj + (lane & 15);
+            const float sc = score_of<false>(st[h][tj][r], i, j, N, g.ws, sBias[wave], sReg[wave], sRC, g.shift, scale);
+            const float p = (i < N) ? __expf(sc - mx) * inv : 0.f;  // P[i][j]; padded queries contribute nothing
+            st[h][tj][r] = p;
+            dp[h][tj][r] = p * (dp[h][tj][r] - dot);                // dS[i][j]
+          }
+        }
+      }
+      // dV^T[e][j] += sum_i dO^T[e][i] P[i][j];  dK^T[e][j] += sum_i Q^T[e][i] dS[i][j]
+#pragma unroll
+      for (int te = 0; te < 2; ++te) {
+        const bf16x8 dt = frag_tr(tD, s2, te, lane), qt = frag_tr(tQ, s2, te, lane);
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) {
+          dv[te][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dt, frag_from_acc(st[0][tj], st[1][tj]), dv[te][tj], 0, 0, 0);
+          dk[te][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, frag_from_acc(dp[0][tj], dp[1][tj]), dk[te][tj], 0, 0, 0);
+        }
+      }
+    }
+    if (uvalid) {
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj) {
+        const int j = 16 * tj + (lane & 15);
+        if (j >= N) continue;
+        bf16* drow = dqkv + (size_t)sTok[wave][j] * 3 * g.C + head * HD;
+#pragma unroll
+        for (int te = 0; te < 2; ++te) {
+          bf16x4 vk, vv;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            vk[r] = (bf16)(dk[te][tj][r] * scale);
+            vv[r] = (bf16)dv[te][tj][r];
+          }
+          *reinterpret_cast<bf16x4*>(drow + g.C + 16 * te + 4 * gq) = vk;
+          *reinterpret_cast<bf16x4*>(drow + 2 * g.C + 16 * te + 4 * gq) = vv;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (dbias_table) {
+    // fold the [i][j] matrix onto the (2ws-1)^2 relative-position bins in LDS, then one global atomic per bin
+    const int off = (g.ws - 1) * (2 * g.ws);
+    for (int i = 0; i < N; ++i)
+      if (lane < N) atomicAdd(&sBin[sRC[i] - sRC[lane] + off], sDB[wave][i * MAXN + lane]);
+    __syncthreads();
+    if ((int)threadIdx.x < nb) atomicAdd(dbias_table + threadIdx.x * g.heads + head, sBin[threadIdx.x]);
+  }
+}
+
 int fill_swin(SwinGeom& g, int B, int H, int W, int C, int heads, int ws, int shift, const char* who) {
   VC_CHECK_SHAPE(B > 0 && H > 0 && W > 0 && ws > 0 && ws * ws <= MAXN && H % ws == 0 && W % ws == 0,
                  "%s: window %d does not tile %dx%d (or exceeds 7x7)", who, ws, H, W);
@@ -359,8 +786,8 @@ int vc_window_attn_fwd(int dtype, const void* qkv, const float* bias_table, void
   if (rc) return rc;
   const int units = B * g.nwh * g.nww * heads;
   if (dtype == VC_BF16)
-    hipLaunchKernelGGL((window_attn_fwd_kernel<bf16>), dim3(units), dim3(64), 0, stream, g, (const bf16*)qkv,
-                       bias_table, (bf16*)out, scale);
+    hipLaunchKernelGGL(window_attn_fwd_mfma_kernel, dim3(ceil_div(units, AW)), dim3(64 * AW), 0, stream, g,
+                       (const bf16*)qkv, bias_table, (bf16*)out, scale, units);
   else if (dtype == VC_F32)
     hipLaunchKernelGGL((window_attn_fwd_kernel<float>), dim3(units), dim3(64), 0, stream, g, (const float*)qkv,
                        bias_table, (float*)out, scale);
@@ -381,9 +808,13 @@ int vc_window_attn_bwd(int dtype, const void* qkv, const void* dout, const float
   int wpb = 1;
   while ((int64_t)ceil_div(windows, wpb) * heads > 8192) wpb *= 2;
   dim3 grid(ceil_div(windows, wpb), heads);
-  if (dtype == VC_BF16)
-    hipLaunchKernelGGL((window_attn_bwd_kernel<bf16>), grid, dim3(64), 0, stream, g, (const bf16*)qkv,
-                       (const bf16*)dout, bias_table, (bf16*)dqkv, dbias_table, scale, windows, wpb);
+  if (dtype == VC_BF16) {
+    int wpw = 1;  // windows per wave: enough blocks to fill the chip, few enough that the bias atomics stay cheap
+    while ((int64_t)ceil_div(windows, AW * wpw) * heads > 1024) wpw *= 2;
+    dim3 mgrid(ceil_div(windows, AW * wpw), heads);
+    hipLaunchKernelGGL(window_attn_bwd_mfma_kernel, mgrid, dim3(64 * AW), 0, stream, g, (const bf16*)qkv,
+                       (const bf16*)dout, bias_table, (bf16*)dqkv, dbias_table, scale, windows, wpw);
+  }
   else if (dtype == VC_F32)
     hipLaunchKernelGGL((window_attn_bwd_kernel<float>), grid, dim3(64), 0, stream, g, (const float*)qkv,
                        (const float*)dout, bias_table, (float*)dqkv, dbias_table, scale, windows, wpb);

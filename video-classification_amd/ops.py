@@ -172,6 +172,19 @@ class _Conv(torch.autograd.Function):
         if weight.numel() != co * ci * taps:
             raise RuntimeError(f"conv: weight of shape {tuple(weight.shape)} is not [Co={co}, Ci={ci}, taps={taps}]")
         wf, wt = _packed_weights(weight, ci, taps, cip, cop, dtype)
+        if taps > 1 and (Do, Ho, Wo) == (1, 1, 1) and p == (0, 0, 0) and k == (D, H, W):
+            # the kernel covers the whole input: a Linear layer over the flattened channels-last map.  Same
+            # forward pack; the data gradient uses a tap-major transposed pack (every tap is valid for exactly
+            # one input pixel, so the gather form would waste taps-1 of every taps products).
+            desc = [N, 1, 1, 1, taps * cip, 1, 1, 1, cop, 1, 1, 1, 1, 1, 1, 0, 0, 0]
+            cache = getattr(weight, "_vc_pack_flat", None)
+            if cache is None or cache[0] is not wf:
+                wt = torch.empty(taps * cip, cop, device=x.device, dtype=dtype)
+                L.call("vc_pack_weight_flat_t", L.dtype_code(dtype), L.ptr(weight.detach()), L.ptr(wt), co, ci, taps,
+                       cip, cop, L.stream())
+                weight._vc_pack_flat = (wf, wt)
+            else:
+                wt = cache[1]
         b = None
         if bias is not None:
             b = bias.detach()
@@ -464,7 +477,7 @@ class _LSTM(torch.autograd.Function):
                 mask = torch.empty(out.shape, device=dev, dtype=torch.uint8)
                 _dropout_seed[0] = (_dropout_seed[0] * 6364136223846793005 + 1442695040888963407) & 0x7FFFFFFFFFFFFFFF
                 L.call("vc_dropout_fwd", code, L.ptr(out), L.ptr(inp), L.ptr(mask), L.i64(out.numel()), float(drop_p),
-                       ctypes.c_uint64(_dropout_seed[0]), st)
+                       ctypes.c_uint64(_dropout_seed[0]), L.ptr(seed_counter(dev)), st)
                 masks[l] = mask
         ctx.masks, ctx.drop_p = masks, drop_p
         ctx.meta = (T, B, In, H, layers, dirs)
@@ -611,6 +624,25 @@ _dropout_seed = [0x5EED]
 def manual_seed(seed):
     """Seed of the dropout generator (counter-based; every call advances it)."""
     _dropout_seed[0] = int(seed) & 0x7FFFFFFFFFFFFFFF
+    for c in _seed_counters.values():
+        c.zero_()
+
+
+# One int64 counter per device, folded into every dropout / drop-path seed at kernel execution time.  The
+# fused optimizer advances it once per step, so a captured graph of the training step draws new masks on
+# every replay although the host-side seed arguments are frozen in the graph.
+_seed_counters = {}
+
+
+def seed_counter(device):
+    c = _seed_counters.get(device)
+    if c is None:
+        c = _seed_counters[device] = torch.zeros(1, device=device, dtype=torch.int64)
+    return c
+
+
+def advance_seed_counter(device):
+    L.call("vc_counter_add", L.ptr(seed_counter(device)), L.i64(1), L.stream())
 
 
 class _Dropout(torch.autograd.Function):
@@ -622,7 +654,7 @@ class _Dropout(torch.autograd.Function):
         mask = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
         _dropout_seed[0] = (_dropout_seed[0] * 6364136223846793005 + 1442695040888963407) & 0x7FFFFFFFFFFFFFFF
         L.call("vc_dropout_fwd", L.dtype_code(x.dtype), L.ptr(x), L.ptr(out), L.ptr(mask), L.i64(x.numel()), float(p),
-               ctypes.c_uint64(_dropout_seed[0]), L.stream())
+               ctypes.c_uint64(_dropout_seed[0]), L.ptr(seed_counter(x.device)), L.stream())
         ctx.p = p
         ctx.save_for_backward(mask)
         return out
@@ -690,7 +722,7 @@ class _DropPath(torch.autograd.Function):
         ctx.args = (float(p), ctypes.c_uint64(_dropout_seed[0]), x.numel() // samples)
         out = torch.empty_like(x)
         L.call("vc_drop_path", L.dtype_code(x.dtype), L.ptr(x), L.ptr(out), L.i64(x.numel()), L.i64(ctx.args[2]),
-               ctx.args[0], ctx.args[1], L.stream())
+               ctx.args[0], ctx.args[1], L.ptr(seed_counter(x.device)), L.stream())
         return out
 
     @staticmethod
@@ -698,7 +730,7 @@ class _DropPath(torch.autograd.Function):
         dy = dy.contiguous()
         dx = torch.empty_like(dy)
         L.call("vc_drop_path", L.dtype_code(dy.dtype), L.ptr(dy), L.ptr(dx), L.i64(dy.numel()), L.i64(ctx.args[2]),
-               ctx.args[0], ctx.args[1], L.stream())
+               ctx.args[0], ctx.args[1], L.ptr(seed_counter(dy.device)), L.stream())
         return dx, None, None
 
 

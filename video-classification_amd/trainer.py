@@ -82,6 +82,12 @@ class FusedOptimizer(torch.optim.Optimizer):
         self.steps = 0
         self.grad_scale = 1.0
         self.bucketer = None
+        # step count and learning rate also live on the device: the kernel reads them at execution time, so a
+        # captured graph of the step keeps working as they change
+        dev = self.flat.data.device
+        self.step_dev = torch.zeros(1, device=dev, dtype=torch.int64)
+        self.lr_dev = torch.full((1,), float(lr), device=dev, dtype=torch.float32)
+        self._lr_host = float(lr)
         for i, p in enumerate(self.flat.params):
             st = self.state[p]
             if self.mode == 2:
@@ -100,14 +106,33 @@ class FusedOptimizer(torch.optim.Optimizer):
     def step(self, closure=None):
         if self.bucketer is not None:
             self.bucketer.finish()
+        self.sync_lr()
+        self.launch()
+        self.after_step()
+
+    def launch(self):
+        """Enqueue the kernels of one optimizer step (no host-side bookkeeping; graph-capturable)."""
         g = self.param_groups[0]
-        self.steps += 1
         b1, b2 = g["betas"]
         if self.mode == 2:
             b1 = g["momentum"]
+        L.call("vc_counter_add", L.ptr(self.step_dev), L.i64(1), L.stream())
         L.call("vc_optim_step", self.mode, L.ptr(self.flat.data), L.ptr(self.flat.grad), L.ptr(self.m), L.ptr(self.v),
                L.i64(self.flat.total), float(g["lr"]), float(b1), float(b2), float(g["eps"]),
-               float(g["weight_decay"]), self.steps, float(self.grad_scale), L.stream())
+               float(g["weight_decay"]), 0, float(self.grad_scale), L.ptr(self.lr_dev), L.ptr(self.step_dev),
+               L.stream())
+        ops.advance_seed_counter(self.flat.data.device)
+
+    def sync_lr(self):
+        """Push the host-side learning rate (param_groups[0]['lr'], e.g. after a scheduler step) to the device."""
+        lr = float(self.param_groups[0]["lr"])
+        if lr != self._lr_host:
+            self.lr_dev.fill_(lr)
+            self._lr_host = lr
+
+    def after_step(self):
+        """Host-side bookkeeping of one optimizer step (also called after a graph replay of the step)."""
+        self.steps += 1
         if self.mode != 2:
             for p in self.flat.params:
                 self.state[p]["step"] += 1
@@ -126,6 +151,9 @@ class FusedOptimizer(torch.optim.Optimizer):
                 self.flat.view_of(self.v, i).copy_(st["exp_avg_sq"])
                 st["exp_avg"], st["exp_avg_sq"] = self.flat.view_of(self.m, i), self.flat.view_of(self.v, i)
                 self.steps = int(st["step"])
+        self.step_dev.fill_(self.steps)
+        self._lr_host = None
+        self.sync_lr()
 
 
 def get_optimizer(model, optimizer_name="adam", lr=0.001, weight_decay=1e-4):
