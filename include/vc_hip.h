@@ -79,11 +79,14 @@ int vc_bn_eval_params(const float* gamma, const float* beta, const float* runnin
                       float* scale, float* shift, int C, float eps, vc_stream_t stream);
 int vc_bn_apply(int dtype, const void* y, const float* scale, const float* shift, const void* residual, void* out,
                 int G, int rpg, int C, int relu, vc_stream_t stream);
+/* backward: with relu set, act (the activation output) supplies the ReLU mask; act == NULL recomputes it as
+ * y*scale+shift > 0, valid when no residual was added in front of the ReLU (one activation read less) */
 int vc_bn_bwd_reduce(int dtype, const void* y, const void* dout, const void* act, const float* mean,
-                     const float* invstd, float* s1, float* s2, int G, int rpg, int C, int relu, vc_stream_t stream);
+                     const float* invstd, const float* scale, const float* shift, float* s1, float* s2, int G, int rpg,
+                     int C, int relu, vc_stream_t stream);
 int vc_bn_bwd_apply(int dtype, const void* y, const void* dout, const void* act, const float* mean,
-                    const float* invstd, const float* scale, const float* s1, const float* s2, void* dy, void* dres,
-                    int G, int rpg, int C, int relu, vc_stream_t stream);
+                    const float* invstd, const float* scale, const float* shift, const float* s1, const float* s2,
+                    void* dy, void* dres, int G, int rpg, int C, int relu, vc_stream_t stream);
 int vc_bn_bwd_params(const float* s1, const float* s2, float* dgamma, float* dbeta, int G, int C, int accumulate,
                      vc_stream_t stream);
 /* nn.LayerNorm inside the Swin-T backbone (timm, created at model_components.py:254, 412) */

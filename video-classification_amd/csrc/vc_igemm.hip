@@ -263,9 +263,15 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_bf16_kernel(ConvGeom g, cons
       if (out_f32) {
         float* op = reinterpret_cast<float*>(out) + o;
         if (beta) {
+          if (full && ((g.ldc & 3) == 0)) {
+            const f32x4 old = *reinterpret_cast<const f32x4*>(op);
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (co + r < g.Co) v[r] += op[r];
+            for (int r = 0; r < 4; ++r) v[r] += old[r];
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (co + r < g.Co) v[r] += op[r];
+          }
         }
         if (relu) {
 #pragma unroll
@@ -281,9 +287,15 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_bf16_kernel(ConvGeom g, cons
       } else {
         bf16* op = reinterpret_cast<bf16*>(out) + o;
         if (beta) {
+          if (full && ((g.ldc & 3) == 0)) {
+            const bf16x4 old = *reinterpret_cast<const bf16x4*>(op);
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (co + r < g.Co) v[r] += (float)op[r];
+            for (int r = 0; r < 4; ++r) v[r] += (float)old[r];
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (co + r < g.Co) v[r] += (float)op[r];
+          }
         }
         if (relu) {
 #pragma unroll

@@ -19,6 +19,7 @@ constexpr int NTHR = 256;
 template <typename T, int MODE>
 __global__ void bn_reduce_kernel(const T* __restrict__ y, const T* __restrict__ dout, const T* __restrict__ act,
                                  const float* __restrict__ mean, const float* __restrict__ invstd,
+                                 const float* __restrict__ scale, const float* __restrict__ shift,
                                  float* __restrict__ s1, float* __restrict__ s2, int C, int rpg, int rows_per_block,
                                  int relu) {
   __shared__ float red[2][NTHR][8];
@@ -37,15 +38,62 @@ __global__ void bn_reduce_kernel(const T* __restrict__ y, const T* __restrict__ 
 #pragma unroll
     for (int i = 0; i < 8; ++i) a1[i] = a2[i] = 0.f;
     if (rl < RL && cvalid) {
-      float mu[8], is[8];
+      float mu[8], is[8], sc[8], sh[8];
       if (MODE == 1) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           mu[i] = mean[g * C + cc * 8 + i];
           is[i] = invstd[g * C + cc * 8 + i];
+          sc[i] = (relu && !act) ? scale[g * C + cc * 8 + i] : 0.f;
+          sh[i] = (relu && !act) ? shift[g * C + cc * 8 + i] : 0.f;
         }
       }
-      for (int r = r_begin + rl; r < r_end; r += RL) {
+      int r = r_begin + rl;
+      if (MODE == 0) {  // four independent 16-byte loads in flight per lane
+        for (; r + 3 * RL < r_end; r += 4 * RL) {
+          const size_t off = ((size_t)g * rpg + r) * C + cc * 8;
+          F8 yv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) yv[u] = load8(y + off + (size_t)u * RL * C);
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              a1[i] += yv[u].v[i];
+              a2[i] = fmaf(yv[u].v[i], yv[u].v[i], a2[i]);
+            }
+        }
+      } else {
+        for (; r + 1 * RL < r_end; r += 2 * RL) {
+          const size_t off = ((size_t)g * rpg + r) * C + cc * 8;
+          F8 yv[2], dv[2], av[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            yv[u] = load8(y + off + (size_t)u * RL * C);
+            dv[u] = load8(dout + off + (size_t)u * RL * C);
+          }
+          if (relu && act) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) av[u] = load8(act + off + (size_t)u * RL * C);
+          }
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            if (relu && act) {
+#pragma unroll
+              for (int i = 0; i < 8; ++i) dv[u].v[i] = av[u].v[i] > 0.f ? dv[u].v[i] : 0.f;
+            } else if (relu) {
+#pragma unroll
+              for (int i = 0; i < 8; ++i) dv[u].v[i] = fmaf(yv[u].v[i], sc[i], sh[i]) > 0.f ? dv[u].v[i] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              a1[i] += dv[u].v[i];
+              a2[i] = fmaf(dv[u].v[i], (yv[u].v[i] - mu[i]) * is[i], a2[i]);
+            }
+          }
+        }
+      }
+      for (; r < r_end; r += RL) {
         const size_t off = ((size_t)g * rpg + r) * C + cc * 8;
         const F8 yv = load8(y + off);
         if (MODE == 0) {
@@ -57,9 +105,14 @@ __global__ void bn_reduce_kernel(const T* __restrict__ y, const T* __restrict__ 
         } else {
           F8 dv = load8(dout + off);
           if (relu) {
-            const F8 av = load8(act + off);
+            if (act) {  // the activation had a residual added: its sign is not a function of y alone
+              const F8 av = load8(act + off);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) dv.v[i] = av.v[i] > 0.f ? dv.v[i] : 0.f;
+              for (int i = 0; i < 8; ++i) dv.v[i] = av.v[i] > 0.f ? dv.v[i] : 0.f;
+            } else {    // recompute the ReLU decision from y (saves one activation read)
+#pragma unroll
+              for (int i = 0; i < 8; ++i) dv.v[i] = fmaf(yv.v[i], sc[i], sh[i]) > 0.f ? dv.v[i] : 0.f;
+            }
           }
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
@@ -140,63 +193,148 @@ __global__ void bn_eval_params_kernel(const float* __restrict__ gamma, const flo
   shift[c] = (beta ? beta[c] : 0.f) - running_mean[c] * sc;
 }
 
+// Row-streaming layout shared by the apply kernels: a block owns `rows_per_block` rows of ONE group and every
+// channel; a thread owns an 8-channel chunk (its per-channel coefficients stay in registers) and walks rows
+// rl, rl+RL, ... four at a time so that several 16-byte loads are in flight per lane.
+struct RowWalk {
+  int lanesC, RL, cl, rl, r_begin, r_end;
+};
+__device__ __forceinline__ RowWalk row_walk(int C8, int rpg, int rows_per_block) {
+  RowWalk w;
+  w.lanesC = C8 < NTHR ? C8 : NTHR;
+  w.RL = NTHR / w.lanesC;
+  w.cl = threadIdx.x % w.lanesC;
+  w.rl = threadIdx.x / w.lanesC;
+  w.r_begin = blockIdx.x * rows_per_block;
+  w.r_end = min(rpg, w.r_begin + rows_per_block);
+  if (w.rl >= w.RL) w.r_end = w.r_begin;  // threads beyond lanesC*RL idle (C8 not a divisor of the block)
+  return w;
+}
+
 // out = act(y * scale[g] + shift[g] (+ residual))
 template <typename T>
-__global__ void bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ scale,
-                                const float* __restrict__ shift, const T* __restrict__ residual, T* __restrict__ out,
-                                int64_t n8, int C8, int rpg, int relu) {
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n8; idx += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t m = idx / C8;
-    const int cc = (int)(idx - m * C8);
-    const int g = (int)(m / rpg);
-    const F8 yv = load8(y + idx * 8);
-    const F8 sc = load8(scale + (size_t)g * C8 * 8 + cc * 8);
-    const F8 sh = load8(shift + (size_t)g * C8 * 8 + cc * 8);
-    F8 o;
+__global__ __launch_bounds__(NTHR) void bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift,
+                                                        const T* __restrict__ residual, T* __restrict__ out, int C,
+                                                        int rpg, int rows_per_block, int relu) {
+  const int C8 = C >> 3, g = blockIdx.y;
+  const RowWalk w = row_walk(C8, rpg, rows_per_block);
+  for (int cc = w.cl; cc < C8; cc += w.lanesC) {
+    const F8 sc = load8(scale + (size_t)g * C + cc * 8), sh = load8(shift + (size_t)g * C + cc * 8);
+    const size_t base = (size_t)g * rpg * C + cc * 8;
+    const size_t rstride = (size_t)w.RL * C;
+    int r = w.r_begin + w.rl;
+    for (; r + 3 * w.RL < w.r_end; r += 4 * w.RL) {
+      const size_t off = base + (size_t)r * C;
+      F8 yv[4], rv[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o.v[i] = fmaf(yv.v[i], sc.v[i], sh.v[i]);
-    if (residual) {
-      const F8 rv = load8(residual + idx * 8);
+      for (int u = 0; u < 4; ++u) yv[u] = load8(y + off + u * rstride);
+      if (residual) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) o.v[i] += rv.v[i];
+        for (int u = 0; u < 4; ++u) rv[u] = load8(residual + off + u * rstride);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        F8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o.v[i] = fmaf(yv[u].v[i], sc.v[i], sh.v[i]);
+        if (residual) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o.v[i] += rv[u].v[i];
+        }
+        if (relu) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o.v[i] = fmaxf(o.v[i], 0.f);
+        }
+        store8(out + off + u * rstride, o);
+      }
     }
-    if (relu) {
+    for (; r < w.r_end; r += w.RL) {
+      const size_t off = base + (size_t)r * C;
+      const F8 yv = load8(y + off);
+      F8 o;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) o.v[i] = fmaxf(o.v[i], 0.f);
+      for (int i = 0; i < 8; ++i) o.v[i] = fmaf(yv.v[i], sc.v[i], sh.v[i]);
+      if (residual) {
+        const F8 rv = load8(residual + off);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o.v[i] += rv.v[i];
+      }
+      if (relu) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o.v[i] = fmaxf(o.v[i], 0.f);
+      }
+      store8(out + off, o);
     }
-    store8(out + idx * 8, o);
   }
 }
 
-// dy = scale * (dz - s1/cnt - xhat * s2/cnt); optionally dres = dz
+// dy = scale * (dz - s1/cnt - xhat * s2/cnt) = ka*dz + kb*y + kc per (group, channel); optionally dres = dz
 template <typename T>
-__global__ void bn_bwd_apply_kernel(const T* __restrict__ y, const T* __restrict__ dout, const T* __restrict__ act,
-                                    const float* __restrict__ mean, const float* __restrict__ invstd,
-                                    const float* __restrict__ scale, const float* __restrict__ s1,
-                                    const float* __restrict__ s2, T* __restrict__ dy, T* __restrict__ dres, int64_t n8,
-                                    int C8, int rpg, float inv_cnt, int relu) {
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n8; idx += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t m = idx / C8;
-    const int cc = (int)(idx - m * C8);
-    const int g = (int)(m / rpg);
-    const size_t po = (size_t)g * C8 * 8 + cc * 8;
-    const F8 yv = load8(y + idx * 8);
-    F8 dv = load8(dout + idx * 8);
-    if (relu) {
-      const F8 av = load8(act + idx * 8);
+__global__ __launch_bounds__(NTHR) void bn_bwd_apply_kernel(
+    const T* __restrict__ y, const T* __restrict__ dout, const T* __restrict__ act, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ s1, const float* __restrict__ s2, T* __restrict__ dy, T* __restrict__ dres, int C,
+    int rpg, int rows_per_block, float inv_cnt, int relu) {
+  const int C8 = C >> 3, g = blockIdx.y;
+  const RowWalk w = row_walk(C8, rpg, rows_per_block);
+  const bool recompute = relu && !act;
+  for (int cc = w.cl; cc < C8; cc += w.lanesC) {
+    const size_t po = (size_t)g * C + cc * 8;
+    const F8 sc = load8(scale + po);
+    F8 sh, kb, kc;
+    {
+      const F8 mu = load8(mean + po), is = load8(invstd + po), a1 = load8(s1 + po), a2 = load8(s2 + po);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) dv.v[i] = av.v[i] > 0.f ? dv.v[i] : 0.f;
+      for (int i = 0; i < 8; ++i) {
+        const float t = sc.v[i] * is.v[i] * a2.v[i] * inv_cnt;
+        kb.v[i] = -t;
+        kc.v[i] = fmaf(t, mu.v[i], -sc.v[i] * a1.v[i] * inv_cnt);
+        sh.v[i] = 0.f;
+      }
+      if (recompute) sh = load8(shift + po);
     }
-    if (dres) store8(dres + idx * 8, dv);
-    const F8 mu = load8(mean + po), is = load8(invstd + po), sc = load8(scale + po), a1 = load8(s1 + po),
-             a2 = load8(s2 + po);
-    F8 o;
+    const size_t base = (size_t)g * rpg * C + cc * 8;
+    const size_t rstride = (size_t)w.RL * C;
+    auto one = [&](size_t off, const F8& yv, F8 dv, const F8& av) {
+      if (relu) {
+        if (recompute) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float xh = (yv.v[i] - mu.v[i]) * is.v[i];
-      o.v[i] = sc.v[i] * (dv.v[i] - a1.v[i] * inv_cnt - xh * a2.v[i] * inv_cnt);
+          for (int i = 0; i < 8; ++i) dv.v[i] = fmaf(yv.v[i], sc.v[i], sh.v[i]) > 0.f ? dv.v[i] : 0.f;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) dv.v[i] = av.v[i] > 0.f ? dv.v[i] : 0.f;
+        }
+      }
+      if (dres) store8(dres + off, dv);
+      F8 o;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o.v[i] = fmaf(sc.v[i], dv.v[i], fmaf(kb.v[i], yv.v[i], kc.v[i]));
+      store8(dy + off, o);
+    };
+    int r = w.r_begin + w.rl;
+    for (; r + 3 * w.RL < w.r_end; r += 4 * w.RL) {
+      const size_t off = base + (size_t)r * C;
+      F8 yv[4], dv[4], av[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        yv[u] = load8(y + off + u * rstride);
+        dv[u] = load8(dout + off + u * rstride);
+      }
+      if (relu && !recompute) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) av[u] = load8(act + off + u * rstride);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) one(off + u * rstride, yv[u], dv[u], av[u]);
     }
-    store8(dy + idx * 8, o);
+    for (; r < w.r_end; r += w.RL) {
+      const size_t off = base + (size_t)r * C;
+      const F8 yv = load8(y + off), dv = load8(dout + off);
+      F8 av = yv;
+      if (relu && !recompute) av = load8(act + off);
+      one(off, yv, dv, av);
+    }
   }
 }
 
@@ -329,20 +467,25 @@ __global__ void ln_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dou
 }
 
 template <typename T, int MODE>
-int launch_reduce(const void* y, const void* dout, const void* act, const float* mean, const float* invstd, float* s1,
-                  float* s2, int G, int rpg, int C, int relu, hipStream_t stream) {
+int launch_reduce(const void* y, const void* dout, const void* act, const float* mean, const float* invstd,
+                  const float* scale, const float* shift, float* s1, float* s2, int G, int rpg, int C, int relu,
+                  hipStream_t stream) {
   int rows_per_block = 256;
   // enough blocks to fill the chip, few enough that the atomics stay cheap
   while (rows_per_block < rpg && (int64_t)ceil_div(rpg, rows_per_block) * G > 2048) rows_per_block *= 2;
   dim3 grid(ceil_div(rpg, rows_per_block), G);
   hipLaunchKernelGGL((bn_reduce_kernel<T, MODE>), grid, dim3(NTHR), 0, stream, (const T*)y, (const T*)dout,
-                     (const T*)act, mean, invstd, s1, s2, C, rpg, rows_per_block, relu);
+                     (const T*)act, mean, invstd, scale, shift, s1, s2, C, rpg, rows_per_block, relu);
   return VC_OK;
 }
 
-inline int ew_grid(int64_t n) {
-  int64_t b = ceil_div64(n, NTHR);
-  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+// rows per block of the apply kernels: a multiple of one unrolled sweep (4*RL rows), sized for >= ~4096 blocks
+inline int apply_rows_per_block(int G, int rpg, int C) {
+  const int C8 = C / 8, lanesC = C8 < NTHR ? C8 : NTHR, RL = NTHR / lanesC;
+  const int sweep = 4 * RL;
+  int rows = sweep;
+  while (rows < 8 * sweep && (int64_t)ceil_div(rpg, rows * 2) * G >= 4096) rows *= 2;
+  return rows;
 }
 
 }  // namespace
@@ -353,8 +496,10 @@ extern "C" {
 int vc_bn_stats(int dtype, const void* y, float* sum, float* sumsq, int G, int rpg, int C, hipStream_t stream) {
   VC_CHECK_ARG(y && sum && sumsq, "vc_bn_stats: null pointer");
   VC_CHECK_SHAPE(C % 8 == 0 && G > 0 && rpg > 0, "vc_bn_stats: need C %% 8 == 0 (C=%d)", C);
-  if (dtype == VC_BF16) launch_reduce<bf16, 0>(y, nullptr, nullptr, nullptr, nullptr, sum, sumsq, G, rpg, C, 0, stream);
-  else if (dtype == VC_F32) launch_reduce<float, 0>(y, nullptr, nullptr, nullptr, nullptr, sum, sumsq, G, rpg, C, 0, stream);
+  if (dtype == VC_BF16)
+    launch_reduce<bf16, 0>(y, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, sum, sumsq, G, rpg, C, 0, stream);
+  else if (dtype == VC_F32)
+    launch_reduce<float, 0>(y, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, sum, sumsq, G, rpg, C, 0, stream);
   else { vc_set_error("vc_bn_stats: unsupported dtype %d", dtype); return VC_ERR_DTYPE; }
   VC_LAUNCH_CHECK("vc_bn_stats");
   return VC_OK;
@@ -385,45 +530,53 @@ int vc_bn_apply(int dtype, const void* y, const float* scale, const float* shift
                 int G, int rpg, int C, int relu, hipStream_t stream) {
   VC_CHECK_ARG(y && scale && shift && out, "vc_bn_apply: null pointer");
   VC_CHECK_SHAPE(C % 8 == 0, "vc_bn_apply: need C %% 8 == 0 (C=%d)", C);
-  const int64_t n8 = (int64_t)G * rpg * (C / 8);
+  VC_CHECK_SHAPE(G > 0 && G < 65536 && rpg > 0, "vc_bn_apply: bad group count %d", G);
+  const int rows = apply_rows_per_block(G, rpg, C);
+  const dim3 grid(ceil_div(rpg, rows), G);
   if (dtype == VC_BF16)
-    hipLaunchKernelGGL((bn_apply_kernel<bf16>), dim3(ew_grid(n8)), dim3(NTHR), 0, stream, (const bf16*)y, scale, shift,
-                       (const bf16*)residual, (bf16*)out, n8, C / 8, rpg, relu);
+    hipLaunchKernelGGL((bn_apply_kernel<bf16>), grid, dim3(NTHR), 0, stream, (const bf16*)y, scale, shift,
+                       (const bf16*)residual, (bf16*)out, C, rpg, rows, relu);
   else if (dtype == VC_F32)
-    hipLaunchKernelGGL((bn_apply_kernel<float>), dim3(ew_grid(n8)), dim3(NTHR), 0, stream, (const float*)y, scale,
-                       shift, (const float*)residual, (float*)out, n8, C / 8, rpg, relu);
+    hipLaunchKernelGGL((bn_apply_kernel<float>), grid, dim3(NTHR), 0, stream, (const float*)y, scale, shift,
+                       (const float*)residual, (float*)out, C, rpg, rows, relu);
   else { vc_set_error("vc_bn_apply: unsupported dtype %d", dtype); return VC_ERR_DTYPE; }
   VC_LAUNCH_CHECK("vc_bn_apply");
   return VC_OK;
 }
 
-// s1/s2 [G][C] must be zeroed by the caller
+// s1/s2 [G][C] must be zeroed by the caller.  With relu set, `act` (the activation output) gives the ReLU mask;
+// act == NULL recomputes it as y*scale+shift > 0 (valid when no residual was added before the ReLU).
 int vc_bn_bwd_reduce(int dtype, const void* y, const void* dout, const void* act, const float* mean,
-                     const float* invstd, float* s1, float* s2, int G, int rpg, int C, int relu, hipStream_t stream) {
-  VC_CHECK_ARG(y && dout && mean && invstd && s1 && s2 && (!relu || act), "vc_bn_bwd_reduce: null pointer");
+                     const float* invstd, const float* scale, const float* shift, float* s1, float* s2, int G, int rpg,
+                     int C, int relu, hipStream_t stream) {
+  VC_CHECK_ARG(y && dout && mean && invstd && s1 && s2 && (!relu || act || (scale && shift)),
+               "vc_bn_bwd_reduce: null pointer");
   VC_CHECK_SHAPE(C % 8 == 0, "vc_bn_bwd_reduce: need C %% 8 == 0 (C=%d)", C);
-  if (dtype == VC_BF16) launch_reduce<bf16, 1>(y, dout, act, mean, invstd, s1, s2, G, rpg, C, relu, stream);
-  else if (dtype == VC_F32) launch_reduce<float, 1>(y, dout, act, mean, invstd, s1, s2, G, rpg, C, relu, stream);
+  if (dtype == VC_BF16) launch_reduce<bf16, 1>(y, dout, act, mean, invstd, scale, shift, s1, s2, G, rpg, C, relu, stream);
+  else if (dtype == VC_F32) launch_reduce<float, 1>(y, dout, act, mean, invstd, scale, shift, s1, s2, G, rpg, C, relu, stream);
   else { vc_set_error("vc_bn_bwd_reduce: unsupported dtype %d", dtype); return VC_ERR_DTYPE; }
   VC_LAUNCH_CHECK("vc_bn_bwd_reduce");
   return VC_OK;
 }
 
 int vc_bn_bwd_apply(int dtype, const void* y, const void* dout, const void* act, const float* mean,
-                    const float* invstd, const float* scale, const float* s1, const float* s2, void* dy, void* dres,
-                    int G, int rpg, int C, int relu, hipStream_t stream) {
-  VC_CHECK_ARG(y && dout && mean && invstd && scale && s1 && s2 && dy && (!relu || act), "vc_bn_bwd_apply: null pointer");
+                    const float* invstd, const float* scale, const float* shift, const float* s1, const float* s2,
+                    void* dy, void* dres, int G, int rpg, int C, int relu, hipStream_t stream) {
+  VC_CHECK_ARG(y && dout && mean && invstd && scale && s1 && s2 && dy && (!relu || act || shift),
+               "vc_bn_bwd_apply: null pointer");
   VC_CHECK_SHAPE(C % 8 == 0, "vc_bn_bwd_apply: need C %% 8 == 0 (C=%d)", C);
-  const int64_t n8 = (int64_t)G * rpg * (C / 8);
+  VC_CHECK_SHAPE(G > 0 && G < 65536 && rpg > 0, "vc_bn_bwd_apply: bad group count %d", G);
   const float inv_cnt = 1.f / (float)rpg;
+  const int rows = apply_rows_per_block(G, rpg, C);
+  const dim3 grid(ceil_div(rpg, rows), G);
   if (dtype == VC_BF16)
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16>), dim3(ew_grid(n8)), dim3(NTHR), 0, stream, (const bf16*)y,
-                       (const bf16*)dout, (const bf16*)act, mean, invstd, scale, s1, s2, (bf16*)dy, (bf16*)dres, n8,
-                       C / 8, rpg, inv_cnt, relu);
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16>), grid, dim3(NTHR), 0, stream, (const bf16*)y, (const bf16*)dout,
+                       (const bf16*)act, mean, invstd, scale, shift, s1, s2, (bf16*)dy, (bf16*)dres, C, rpg, rows,
+                       inv_cnt, relu);
   else if (dtype == VC_F32)
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(ew_grid(n8)), dim3(NTHR), 0, stream, (const float*)y,
-                       (const float*)dout, (const float*)act, mean, invstd, scale, s1, s2, (float*)dy, (float*)dres,
-                       n8, C / 8, rpg, inv_cnt, relu);
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), grid, dim3(NTHR), 0, stream, (const float*)y, (const float*)dout,
+                       (const float*)act, mean, invstd, scale, shift, s1, s2, (float*)dy, (float*)dres, C, rpg, rows,
+                       inv_cnt, relu);
   else { vc_set_error("vc_bn_bwd_apply: unsupported dtype %d", dtype); return VC_ERR_DTYPE; }
   VC_LAUNCH_CHECK("vc_bn_bwd_apply");
   return VC_OK;

@@ -113,13 +113,16 @@ class Bottleneck(nn.Module):
 
     def run(self, x, T):
         s = self.stride
-        a = ops.batch_norm(ops.conv(x, self.conv1.weight), self.bn1, T, relu=True)
+        # x feeds conv1 and the shortcut: both backward paths add into one gradient buffer (no add pass)
+        join = ops.GradJoin(2) if (x.requires_grad and torch.is_grad_enabled()) else None
+        a = ops.batch_norm(ops.conv(x, self.conv1.weight, join=join), self.bn1, T, relu=True)
         a = ops.batch_norm(ops.conv(a, self.conv2.weight, None, (1, 3, 3), (1, s, s), (0, 1, 1)), self.bn2, T, relu=True)
         y = ops.conv(a, self.conv3.weight)
-        idt = x
         if self.downsample is not None:
-            idt = ops.batch_norm(ops.conv(x, self.downsample[0].weight, None, 1, (1, s, s), 0), self.downsample[1], T)
-        return ops.batch_norm(y, self.bn3, T, relu=True, residual=idt)
+            idt = ops.batch_norm(ops.conv(x, self.downsample[0].weight, None, 1, (1, s, s), 0, join=join),
+                                 self.downsample[1], T)
+            return ops.batch_norm(y, self.bn3, T, relu=True, residual=idt)
+        return ops.batch_norm(y, self.bn3, T, relu=True, residual=x, res_join=join)
 
 
 RESNET_LAYERS = {"resnet50": (3, 4, 6, 3), "resnet101": (3, 4, 23, 3), "resnet152": (3, 8, 36, 3)}

@@ -155,8 +155,9 @@ class _Conv(torch.autograd.Function):
     """y = conv(x, weight) + bias (optionally ReLU) on channels-last tensors."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, kernel, stride, padding, relu, out_f32, ci):
+    def forward(ctx, x, weight, bias, kernel, stride, padding, relu, out_f32, ci, join):
         _require_cuda(x, "conv")
+        ctx.join = join
         x = x.contiguous()
         dtype = x.dtype
         N, D, H, W, cip = x.shape
@@ -227,17 +228,41 @@ class _Conv(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if cip != ci:
                 raise RuntimeError("conv: data gradient requested for a channel-padded input")
-            dx = torch.empty_like(x)
+            join = ctx.join
+            acc = join is not None and join.buf is not None
+            dx = join.buf if acc else torch.empty_like(x)
             _timed("conv_dgrad", ctx.flops, lambda: L.call(
-                "vc_conv_dgrad", desc, code, L.ptr(dy), 0, L.ptr(wt), L.ptr(dx), 0, int(dtype == torch.float32), 0,
-                L.stream()))
-        return dx, None, None, None, None, None, None, None, None
+                "vc_conv_dgrad", desc, code, L.ptr(dy), 0, L.ptr(wt), L.ptr(dx), 0, int(dtype == torch.float32),
+                int(acc), L.stream()))
+            if join is not None:
+                dx = join.arrive(dx)
+        return dx, None, None, None, None, None, None, None, None, None
 
 
-def conv(x, weight, bias=None, kernel=1, stride=1, padding=0, relu=False, out_f32=False, ci=None):
+class GradJoin:
+    """Gradient accumulator of an activation that has several consumers (the input of a residual block).
+    Each consumer's backward adds its contribution into ONE buffer inside its own kernel (the data-gradient
+    GEMM accumulates in its epilogue) and only the last consumer to arrive hands the buffer to autograd, so
+    no separate elementwise add pass runs over the activation."""
+
+    def __init__(self, consumers):
+        self.pending = consumers
+        self.buf = None
+
+    def arrive(self, buf):
+        self.buf = buf
+        self.pending -= 1
+        if self.pending == 0:
+            self.buf = None
+            return buf
+        return None
+
+
+def conv(x, weight, bias=None, kernel=1, stride=1, padding=0, relu=False, out_f32=False, ci=None, join=None):
     """x: [N,D,H,W,C] channels-last.  weight: fp32 parameter whose memory is [Co][Ci][taps] (a Conv2d/Conv3d
-    weight, or a Linear weight [Co, Ci*taps] read as a convolution over the whole feature map when `ci` is given)."""
-    return _Conv.apply(x, weight, bias, kernel, stride, padding, relu, out_f32, ci)
+    weight, or a Linear weight [Co, Ci*taps] read as a convolution over the whole feature map when `ci` is given).
+    join: optional GradJoin shared with the other consumers of x."""
+    return _Conv.apply(x, weight, bias, kernel, stride, padding, relu, out_f32, ci, join)
 
 
 def linear(x, weight, bias=None, relu=False, out_f32=False):
@@ -252,8 +277,10 @@ def linear(x, weight, bias=None, relu=False, out_f32=False):
 # ----------------------------------------------------------------------------------------------
 class _BatchNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, groups, momentum, eps, relu, residual, training):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, groups, momentum, eps, relu, residual, training,
+                res_join):
         _require_cuda(y, "batch_norm")
+        ctx.res_join = res_join
         y = y.contiguous()
         C = y.shape[-1]
         M = y.numel() // C
@@ -285,7 +312,8 @@ class _BatchNorm(torch.autograd.Function):
         ctx.G, ctx.rpg, ctx.C, ctx.relu, ctx.training = G, rpg, C, relu, training
         ctx.has_res = residual is not None
         ctx.gamma, ctx.beta = gamma, beta
-        ctx.save_for_backward(y, out if relu else None, stat)
+        # the ReLU mask is recomputed from y in backward unless a residual entered in front of the ReLU
+        ctx.save_for_backward(y, out if (relu and residual is not None) else None, stat)
         return out
 
     @staticmethod
@@ -297,25 +325,33 @@ class _BatchNorm(torch.autograd.Function):
         code = L.dtype_code(y.dtype)
         dout = cast(dout.contiguous(), y.dtype)
         s = torch.zeros(2, G, C, device=y.device, dtype=torch.float32)
-        L.call("vc_bn_bwd_reduce", code, L.ptr(y), L.ptr(dout), L.ptr(out), L.ptr(stat[0]), L.ptr(stat[1]), L.ptr(s[0]),
-               L.ptr(s[1]), G, rpg, C, int(ctx.relu), L.stream())
+        L.call("vc_bn_bwd_reduce", code, L.ptr(y), L.ptr(dout), L.ptr(out), L.ptr(stat[0]), L.ptr(stat[1]),
+               L.ptr(stat[2]), L.ptr(stat[3]), L.ptr(s[0]), L.ptr(s[1]), G, rpg, C, int(ctx.relu), L.stream())
         dy = torch.empty_like(y)
         dres = torch.empty_like(y) if ctx.has_res else None
         L.call("vc_bn_bwd_apply", code, L.ptr(y), L.ptr(dout), L.ptr(out), L.ptr(stat[0]), L.ptr(stat[1]),
-               L.ptr(stat[2]), L.ptr(s[0]), L.ptr(s[1]), L.ptr(dy), L.ptr(dres), G, rpg, C, int(ctx.relu), L.stream())
+               L.ptr(stat[2]), L.ptr(stat[3]), L.ptr(s[0]), L.ptr(s[1]), L.ptr(dy), L.ptr(dres), G, rpg, C,
+               int(ctx.relu), L.stream())
+        join = ctx.res_join
+        if join is not None and dres is not None:
+            if join.buf is not None:
+                dres = elementwise(0, join.buf, dres)
+            dres = join.arrive(dres)
         dg = _grad_buf(ctx.gamma) if ctx.gamma is not None and ctx.gamma.requires_grad else None
         db = _grad_buf(ctx.beta) if ctx.beta is not None and ctx.beta.requires_grad else None
         if dg is not None or db is not None:
             L.call("vc_bn_bwd_params", L.ptr(s[0]), L.ptr(s[1]), L.ptr(dg), L.ptr(db), G, C, 1, L.stream())
         _ready(ctx.gamma, ctx.beta)
-        return dy, None, None, None, None, None, None, None, None, dres, None
+        return dy, None, None, None, None, None, None, None, None, dres, None, None
 
 
-def batch_norm(y, bn, groups, relu=False, residual=None):
-    """bn: an nn.BatchNorm{1,2,3}d module holding the parameters/buffers (its own forward is not used)."""
+def batch_norm(y, bn, groups, relu=False, residual=None, res_join=None):
+    """bn: an nn.BatchNorm{1,2,3}d module holding the parameters/buffers (its own forward is not used).
+    res_join: optional GradJoin shared with the other consumers of `residual`."""
     training = bn.training or bn.running_mean is None
     out = _BatchNorm.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, groups,
-                           bn.momentum if bn.momentum is not None else 0.1, bn.eps, relu, residual, training)
+                           bn.momentum if bn.momentum is not None else 0.1, bn.eps, relu, residual, training,
+                           res_join)
     if training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked += groups
     return out
