@@ -98,6 +98,12 @@ def test_conv_fwd_dgrad_wgrad(cuda, case, dt):
     L.call("vc_conv_dgrad", d, code, L.ptr(dyd), 0, L.ptr(wt), L.ptr(dx), 0, 1, 0, L.stream())
     torch.cuda.synchronize()
     assert _rel(dx.cpu(), _to_ndhwc(xr.grad)) < tol
+    # accumulate into what dx holds (beta = 1), compute-type output: dx0 + dgrad
+    dx0 = torch.randn(N, D, H, W, Ci, generator=g).to(cuda, dt)
+    dxa = dx0.clone()
+    L.call("vc_conv_dgrad", d, code, L.ptr(dyd), 0, L.ptr(wt), L.ptr(dxa), 0, int(dt == torch.float32), 1, L.stream())
+    torch.cuda.synchronize()
+    assert _rel(dxa.float().cpu(), _to_ndhwc(xr.grad) + dx0.float().cpu()) < (1e-2 if dt == torch.bfloat16 else tol)
 
     # weight gradient (MFMA path for bf16, naive path for fp32)
     dwp = torch.zeros(Co, taps, Ci, device=cuda, dtype=torch.float32)

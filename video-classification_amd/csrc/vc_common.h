@@ -172,4 +172,11 @@ struct ConvGeom {
   int ldi;  // row (pixel) stride of the gather source, in elements (>= Ci)
   FastDiv fWo, fHo, fDo;  // pixel index -> (n, od, oh, ow)
   FastDiv fC8, fkw, fkh;  // k-chunk index -> (tap, c) -> (rd, rh, rw)
+  // Phase view (data gradient of a strided convolution, one GEMM per output phase): the GEMM's taps
+  // (ah, aw) are every stride-th tap of the packed weight and its rows (hc, wc) every stride-th output pixel.
+  int ldw;                         // row stride of the packed weight, in elements
+  int wt_kh, wt_kw;                // kernel extent of the packed weight
+  int wt_h0, wt_hs, wt_w0, wt_ws;  // weight tap rh = wt_h0 + wt_hs*ah, rw = wt_w0 + wt_ws*aw
+  int oHo, oWo;                    // extent of the image the output rows live in
+  int o_h0, o_hs, o_w0, o_ws;      // output pixel h = o_h0 + o_hs*hc, w = o_w0 + o_ws*wc
 };

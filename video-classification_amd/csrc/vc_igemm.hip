@@ -9,6 +9,10 @@
 //   * igemm_nt: out[pixel][co] = sum_k gather(src)[pixel][k] * wgt[co][k]
 //       MODE 0: forward gather (in = out*stride - pad + tap)
 //       MODE 1: data-gradient gather (in = (out + pad - tap)/stride when divisible)
+//       MODE 2: one output phase of a strided data gradient: the rows are the dx pixels with
+//               (h, w) = phase (mod stride) and only the taps that reach them are in the
+//               reduction (a stride-1 MODE 1 gather over a sub-sampled kernel), so no
+//               product is spent on a tap that fails the divisibility test
 //     128x128x64 tiles, 4 waves (2x2), 4x4 v_mfma_f32_16x16x32_bf16 tiles per wave,
 //     register-staged global->LDS double buffering, XOR-swizzled 128-byte LDS rows.
 //   * igemm_tn (weight gradient): dw[co][k] += sum_pixel dy[pixel][co] * gather(x)[pixel][k]
@@ -54,7 +58,7 @@ __device__ __forceinline__ RowPos decode_row(const ConvGeom& g, int m) {
     r.d0 = od * g.sd - g.pd;
     r.h0 = oh * g.sh - g.ph;
     r.w0 = ow * g.sw - g.pw;
-  } else {
+  } else {  // MODE 1 and 2
     r.d0 = od + g.pd;
     r.h0 = oh + g.ph;
     r.w0 = ow + g.pw;
@@ -62,12 +66,26 @@ __device__ __forceinline__ RowPos decode_row(const ConvGeom& g, int m) {
   return r;
 }
 
+// output pixel (row of the output matrix) of GEMM row m in a phase view
+__device__ __forceinline__ int phase_out_pixel(const ConvGeom& g, int m) {
+  int t, wc, hc, od;
+  fd_divmod(m, g.fWo, t, wc);
+  fd_divmod(t, g.fHo, t, hc);
+  fd_divmod(t, g.fDo, t, od);
+  return ((t * g.Do + od) * g.oHo + g.o_h0 + g.o_hs * hc) * g.oWo + g.o_w0 + g.o_ws * wc;
+}
+
 // Offset (in elements) of the source pixel for row r and tap (rd, rh, rw); -1 if the
 // tap falls outside the source (zero padding / no contributing output).
 template <int MODE>
 __device__ __forceinline__ int gather_pixel(const ConvGeom& g, const RowPos& r, int rd, int rh, int rw) {
   int id, ih, iw;
-  if (MODE == 0) {
+  if (MODE == 2) {
+    id = r.d0 - rd;
+    ih = r.h0 - rh;
+    iw = r.w0 - rw;
+    if ((unsigned)id >= (unsigned)g.Di || (unsigned)ih >= (unsigned)g.Hi || (unsigned)iw >= (unsigned)g.Wi) return -1;
+  } else if (MODE == 0) {
     id = r.d0 + rd;
     ih = r.h0 + rh;
     iw = r.w0 + rw;
@@ -90,6 +108,13 @@ __device__ __forceinline__ void decode_chunk(const ConvGeom& g, int kc, int& rd,
   c = c8 * 8;
   fd_divmod(tap, g.fkw, t2, rw);
   fd_divmod(t2, g.fkh, rd, rh);
+}
+
+// column (element offset inside a packed weight row) of k-chunk kc = (rd, rh, rw, c)
+template <int MODE>
+__device__ __forceinline__ int weight_col(const ConvGeom& g, int kc, int rd, int rh, int rw, int c) {
+  if (MODE != 2) return kc * 8;
+  return ((rd * g.wt_kh + g.wt_h0 + g.wt_hs * rh) * g.wt_kw + g.wt_w0 + g.wt_ws * rw) * g.Ci + c;
 }
 
 // ----------------------------------------------------------------------------
@@ -152,6 +177,7 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_bf16_kernel(ConvGeom g, cons
     const bool kvalid = kc * 8 < g.K;
     int rd, rh, rw, c;
     decode_chunk(g, kc, rd, rh, rw, c);
+    const int wcol = weight_col<MODE>(g, kc, rd, rh, rw, c);
     bf16* sA = smem + buf * (BM + BN) * BK;
     bf16* sW = sA + BM * BK;
 #pragma unroll
@@ -161,7 +187,7 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_bf16_kernel(ConvGeom g, cons
       if (kvalid && pix >= 0) asrc = src + (size_t)pix * g.ldi + c;
       const void* wsrc = vc_zero_src;
       const int co = n0 + lrow + 32 * i;
-      if (kvalid && co < g.Co) wsrc = wgt + (size_t)co * g.K + kc * 8;
+      if (kvalid && co < g.Co) wsrc = wgt + (size_t)co * g.ldw + wcol;
       // this wave's instruction fills rows [32*i + 8*wave, +8): 8 rows x 128 B = 64 lanes x 16 B
       glds16(asrc, sA + (32 * i + 8 * wave) * BK);
       glds16(wsrc, sW + (32 * i + 8 * wave) * BK);
@@ -172,6 +198,7 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_bf16_kernel(ConvGeom g, cons
     const bool kvalid = kc * 8 < g.K;
     int rd, rh, rw, c;
     decode_chunk(g, kc, rd, rh, rw, c);
+    const int wcol = weight_col<MODE>(g, kc, rd, rh, rw, c);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -180,7 +207,7 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_bf16_kernel(ConvGeom g, cons
       areg[i] = v;
       bf16x8 w = {0, 0, 0, 0, 0, 0, 0, 0};
       const int co = n0 + lrow + 32 * i;
-      if (kvalid && co < g.Co) w = *reinterpret_cast<const bf16x8*>(wgt + (size_t)co * g.K + kc * 8);
+      if (kvalid && co < g.Co) w = *reinterpret_cast<const bf16x8*>(wgt + (size_t)co * g.ldw + wcol);
       wreg[i] = w;
     }
   };
@@ -253,7 +280,7 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_bf16_kernel(ConvGeom g, cons
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
-      const size_t o = (size_t)m * g.ldc + co;
+      const size_t o = (size_t)(MODE == 2 ? phase_out_pixel(g, m) : m) * g.ldc + co;
       const bool full = (co + 3 < g.Co);
       if (bias) {
 #pragma unroll
@@ -620,6 +647,7 @@ int fill_geom(ConvGeom& g, const int* d, int mode, const char* who) {
     g.Co = ci;
   }
   g.K = kd * kh * kw * g.Ci;
+  g.ldw = g.K;
   g.M = g.N * g.Do * g.Ho * g.Wo;
   g.ldc = g.Co;
   g.ldi = g.Ci;
@@ -692,6 +720,36 @@ int vc_conv_dgrad(const int* desc, int dtype, const void* dy, int lddy, const vo
   if (lddy > 0) g.ldi = lddy;
   VC_CHECK_SHAPE(g.ldc >= g.Co && g.ldi >= g.Ci, "vc_conv_dgrad: leading dimension smaller than channel count");
   VC_CHECK_SHAPE(dtype != VC_BF16 || g.ldi % 8 == 0, "vc_conv_dgrad: bf16 path needs lddy %% 8 == 0");
+  if (dtype == VC_BF16 && g.sd == 1 && (g.sh > 1 || g.sw > 1)) {
+    // one GEMM per output phase (h mod sh, w mod sw): its reduction holds exactly the taps that reach the phase
+    for (int a = 0; a < g.sh && a < g.Ho; ++a) {
+      for (int b = 0; b < g.sw && b < g.Wo; ++b) {
+        ConvGeom c = g;
+        const int rh0 = (a + g.ph) % g.sh, rw0 = (b + g.pw) % g.sw;
+        const int nth = rh0 < g.kh ? (g.kh - rh0 + g.sh - 1) / g.sh : 0;
+        const int ntw = rw0 < g.kw ? (g.kw - rw0 + g.sw - 1) / g.sw : 0;
+        if (nth * ntw == 0 && beta) continue;  // nothing reaches this phase and dx keeps what it holds
+        const int Hc = (g.Ho - a + g.sh - 1) / g.sh, Wc = (g.Wo - b + g.sw - 1) / g.sw;
+        c.oHo = g.Ho; c.oWo = g.Wo;
+        c.o_h0 = a; c.o_hs = g.sh; c.o_w0 = b; c.o_ws = g.sw;
+        c.wt_kh = g.kh; c.wt_kw = g.kw;
+        c.wt_h0 = rh0; c.wt_hs = g.sh; c.wt_w0 = rw0; c.wt_ws = g.sw;
+        c.Ho = Hc; c.Wo = Wc;
+        c.kh = nth; c.kw = ntw;
+        c.sh = c.sw = 1;
+        c.ph = (a + g.ph) / g.sh; c.pw = (b + g.pw) / g.sw;
+        c.K = g.kd * nth * ntw * g.Ci;  // 0: the phase is written with zeros
+        c.M = g.N * g.Do * Hc * Wc;
+        c.fWo = make_fastdiv(Wc);
+        c.fHo = make_fastdiv(Hc);
+        c.fkw = make_fastdiv(ntw > 0 ? ntw : 1);
+        c.fkh = make_fastdiv(nth > 0 ? nth : 1);
+        rc = launch_nt<2>(c, dtype, dy, w_packed_t, nullptr, dx, 0, out_f32, beta, stream, "vc_conv_dgrad");
+        if (rc) return rc;
+      }
+    }
+    return VC_OK;
+  }
   return launch_nt<1>(g, dtype, dy, w_packed_t, nullptr, dx, 0, out_f32, beta, stream, "vc_conv_dgrad");
 }
 

@@ -115,12 +115,16 @@ class Bottleneck(nn.Module):
         s = self.stride
         # x feeds conv1 and the shortcut: both backward paths add into one gradient buffer (no add pass)
         join = ops.GradJoin(2) if (x.requires_grad and torch.is_grad_enabled()) else None
+        idt = None
+        if self.downsample is not None:
+            # evaluated before conv1 so that its backward runs after conv1's: the strided 1x1 data gradient then
+            # only ADDS into the pixels it reaches instead of also zero-filling the rest of the buffer
+            idt = ops.batch_norm(ops.conv(x, self.downsample[0].weight, None, 1, (1, s, s), 0, join=join),
+                                 self.downsample[1], T)
         a = ops.batch_norm(ops.conv(x, self.conv1.weight, join=join), self.bn1, T, relu=True)
         a = ops.batch_norm(ops.conv(a, self.conv2.weight, None, (1, 3, 3), (1, s, s), (0, 1, 1)), self.bn2, T, relu=True)
         y = ops.conv(a, self.conv3.weight)
-        if self.downsample is not None:
-            idt = ops.batch_norm(ops.conv(x, self.downsample[0].weight, None, 1, (1, s, s), 0, join=join),
-                                 self.downsample[1], T)
+        if idt is not None:
             return ops.batch_norm(y, self.bn3, T, relu=True, residual=idt)
         return ops.batch_norm(y, self.bn3, T, relu=True, residual=x, res_join=join)
 
