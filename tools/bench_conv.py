@@ -46,13 +46,18 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=512)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--only", default=None, help="run only the layer with this name (for counter collection)")
+    ap.add_argument("--passes", default="fwd,dgrad,wgrad")
     args = ap.parse_args()
+    passes = args.passes.split(",")
     dev = torch.device("cuda:0")
     dt = torch.bfloat16
     tot = {"fwd": [0.0, 0.0], "dgrad": [0.0, 0.0], "wgrad": [0.0, 0.0]}
     print(f"{'layer':12s} {'N,H,W,Ci->Co k s':34s} {'cnt':>3s} {'GF':>8s} | {'fwd TF':>7s} {'ms':>6s} | {'dgrad TF':>8s} {'ms':>6s} |"
           f" {'wgrad TF':>8s} {'ms':>6s}")
     for name, N, H, W, Ci, Co, k, s, p, cnt in resnet50_shapes(args.frames):
+        if args.only and name != args.only:
+            continue
         cip = (Ci + 7) // 8 * 8
         Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
         desc = L.int_array([N, 1, H, W, cip, 1, Ho, Wo, Co, 1, k, k, 1, s, s, 0, p, p])
@@ -78,11 +83,13 @@ def main():
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) / args.reps
 
-        t_f = run(lambda: L.call("vc_conv_fwd", desc, 1, L.ptr(x), 0, L.ptr(wf), L.ptr(None), L.ptr(y), 0, 0, 0, 0, st))
-        t_d = float("nan")
-        if Ci % 8 == 0:
+        t_f = t_d = t_w = float("nan")
+        if "fwd" in passes:
+            t_f = run(lambda: L.call("vc_conv_fwd", desc, 1, L.ptr(x), 0, L.ptr(wf), L.ptr(None), L.ptr(y), 0, 0, 0, 0, st))
+        if Ci % 8 == 0 and "dgrad" in passes:
             t_d = run(lambda: L.call("vc_conv_dgrad", desc, 1, L.ptr(dy), 0, L.ptr(wt), L.ptr(dx), 0, 0, 0, st))
-        t_w = run(lambda: L.call("vc_conv_wgrad", desc, 1, L.ptr(x), 0, L.ptr(dy), 0, L.ptr(dwp), 0, st))
+        if "wgrad" in passes:
+            t_w = run(lambda: L.call("vc_conv_wgrad", desc, 1, L.ptr(x), 0, L.ptr(dy), 0, L.ptr(dwp), 0, st))
         tf = lambda t: flops / (t * 1e-3) / 1e12  # noqa: E731
         print(f"{name:12s} {f'{N},{H},{W},{Ci}->{Co} k{k} s{s}':34s} {cnt:3d} {flops / 1e9:8.1f} | {tf(t_f):7.0f} {t_f:6.3f} | "
               f"{tf(t_d):8.0f} {t_d:6.3f} | {tf(t_w):8.0f} {t_w:6.3f}")
@@ -91,7 +98,8 @@ def main():
                 tot[key][0] += flops * cnt
                 tot[key][1] += t * cnt
     for key, (fl, ms) in tot.items():
-        print(f"total {key:6s}: {ms:7.2f} ms per step, {fl / (ms * 1e-3) / 1e12:6.0f} TFLOP/s")
+        if ms > 0:
+            print(f"total {key:6s}: {ms:7.2f} ms per step, {fl / (ms * 1e-3) / 1e12:6.0f} TFLOP/s")
 
 
 if __name__ == "__main__":

@@ -142,6 +142,82 @@ __device__ __forceinline__ void glds16(const void* g, bf16* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
+// Epilogue shared by the NT kernels: a lane holds 4 consecutive channels of one pixel per 16x16 tile.
+template <int MODE>
+__device__ __forceinline__ void nt_epilogue(const ConvGeom& g, f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn,
+                                            int lane, const float* __restrict__ bias, void* __restrict__ out,
+                                            int relu, int out_f32, int beta) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = m0 + wm * 64 + j * 16 + (lane & 15);
+    if (m >= g.M) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int co = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
+      if (co >= g.Co) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
+      const size_t o = (size_t)(MODE == 2 ? phase_out_pixel(g, m) : m) * g.ldc + co;
+      const bool full = (co + 3 < g.Co);
+      if (bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (co + r < g.Co) v[r] += bias[co + r];
+      }
+      if (out_f32) {
+        float* op = reinterpret_cast<float*>(out) + o;
+        if (beta) {
+          if (full && ((g.ldc & 3) == 0)) {
+            const f32x4 old = *reinterpret_cast<const f32x4*>(op);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += old[r];
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (co + r < g.Co) v[r] += op[r];
+          }
+        }
+        if (relu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (full && ((g.ldc & 3) == 0)) {
+          *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (co + r < g.Co) op[r] = v[r];
+        }
+      } else {
+        bf16* op = reinterpret_cast<bf16*>(out) + o;
+        if (beta) {
+          if (full && ((g.ldc & 3) == 0)) {
+            const bf16x4 old = *reinterpret_cast<const bf16x4*>(op);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += (float)old[r];
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (co + r < g.Co) v[r] += (float)op[r];
+          }
+        }
+        if (relu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (full && ((g.ldc & 3) == 0)) {
+          *reinterpret_cast<bf16x4*>(op) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (co + r < g.Co) op[r] = (bf16)v[r];
+        }
+      }
+    }
+  }
+}
+
 // GLDS = true : tiles are staged global -> LDS by LDS-DMA (no VGPR round trip, no ds_write); the XOR
 //               swizzle of the LDS image is applied to each lane's SOURCE address.
 // GLDS = false: register-staged variant (global_load -> VGPR -> ds_write), kept for A/B measurements.
@@ -268,76 +344,135 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_bf16_kernel(ConvGeom g, cons
     __syncthreads();
   }
 
-  // Epilogue: lane holds 4 consecutive channels of one pixel per 16x16 tile.
+  nt_epilogue<MODE>(g, acc, m0, n0, wm, wn, lane, bias, out, relu, out_f32, beta);
+}
+
+// NT kernel for source channel counts that are a multiple of BK (every layer past a network's first): a
+// k-tile then lies inside ONE tap, so the tap decode and the bounds tests run once per tap (on uniform
+// values where possible) and the per-tile address work is one pointer increment per staged row.
+template <int MODE>
+__global__ __launch_bounds__(NTHR, 2) void igemm_nt_fast_kernel(ConvGeom g, const bf16* __restrict__ src,
+                                                                const bf16* __restrict__ wgt,
+                                                                const float* __restrict__ bias, void* __restrict__ out,
+                                                                int relu, int out_f32, int beta) {
+  __shared__ __attribute__((aligned(1024))) bf16 smem[2 * (BM + BN) * BK];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = (g.Co + BN - 1) / BN;
+  int logical;
+  xcd_remap(logical);
+  const int tile_m = logical / tiles_n, tile_n = logical - tile_m * tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int lrow = tid >> 3, pchunk = tid & 7;
+  const int lchunk = pchunk ^ ((lrow >> 1) & 7);
+  RowPos rp[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int m = m0 + wm * 64 + j * 16 + (lane & 15);
-    if (m >= g.M) continue;
+  for (int i = 0; i < 4; ++i) rp[i] = decode_row<MODE>(g, m0 + lrow + 32 * i);
+
+  const int ncb = g.Ci / BK;  // k-tiles per tap
+  const int nk = g.K / BK;
+  const bf16* zero = reinterpret_cast<const bf16*>(vc_zero_src);
+
+  // staged-row pointers: advance by BK elements per k-tile inside a tap; rows that read padding (or lie
+  // beyond the matrix) point at the zero page and do not advance
+  const bf16* ap[4];
+  const bf16* wp[4];
+  int ainc[4], winc[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int co = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
-      if (co >= g.Co) continue;
-      float v[4];
+  for (int i = 0; i < 4; ++i) {
+    const int co = n0 + lrow + 32 * i;
+    const bool ok = co < g.Co;
+    wp[i] = ok ? wgt + (size_t)co * g.ldw + lchunk * 8 : zero;
+    winc[i] = ok ? BK : 0;
+    ap[i] = zero;
+    ainc[i] = 0;
+  }
+  int tap = 0, cb = 0;  // uniform over the block
+
+  auto stage = [&](int buf) {
+    if (cb == 0) {
+      int t2, rd, rh, rw;
+      fd_divmod(tap, g.fkw, t2, rw);
+      fd_divmod(t2, g.fkh, rd, rh);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
-      const size_t o = (size_t)(MODE == 2 ? phase_out_pixel(g, m) : m) * g.ldc + co;
-      const bool full = (co + 3 < g.Co);
-      if (bias) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (co + r < g.Co) v[r] += bias[co + r];
+      for (int i = 0; i < 4; ++i) {
+        const int pix = gather_pixel<MODE>(g, rp[i], rd, rh, rw);
+        const bool ok = pix >= 0;
+        ap[i] = ok ? src + (size_t)pix * g.ldi + lchunk * 8 : zero;
+        ainc[i] = ok ? BK : 0;
       }
-      if (out_f32) {
-        float* op = reinterpret_cast<float*>(out) + o;
-        if (beta) {
-          if (full && ((g.ldc & 3) == 0)) {
-            const f32x4 old = *reinterpret_cast<const f32x4*>(op);
+      if (MODE == 2) {  // the taps of a phase are not adjacent in the packed weight row
+        const int wcol = ((rd * g.wt_kh + g.wt_h0 + g.wt_hs * rh) * g.wt_kw + g.wt_w0 + g.wt_ws * rw) * g.Ci;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += old[r];
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (co + r < g.Co) v[r] += op[r];
-          }
-        }
-        if (relu) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-        }
-        if (full && ((g.ldc & 3) == 0)) {
-          *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (co + r < g.Co) op[r] = v[r];
-        }
-      } else {
-        bf16* op = reinterpret_cast<bf16*>(out) + o;
-        if (beta) {
-          if (full && ((g.ldc & 3) == 0)) {
-            const bf16x4 old = *reinterpret_cast<const bf16x4*>(op);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += (float)old[r];
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (co + r < g.Co) v[r] += (float)op[r];
-          }
-        }
-        if (relu) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-        }
-        if (full && ((g.ldc & 3) == 0)) {
-          *reinterpret_cast<bf16x4*>(op) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (co + r < g.Co) op[r] = (bf16)v[r];
+        for (int i = 0; i < 4; ++i) {
+          const int co = n0 + lrow + 32 * i;
+          if (co < g.Co) wp[i] = wgt + (size_t)co * g.ldw + wcol + lchunk * 8;
         }
       }
     }
+    bf16* sA = smem + buf * (BM + BN) * BK;
+    bf16* sW = sA + BM * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16(ap[i], sA + (32 * i + 8 * wave) * BK);
+      glds16(wp[i], sW + (32 * i + 8 * wave) * BK);
+      ap[i] += ainc[i];
+      wp[i] += winc[i];
+    }
+    if (++cb == ncb) {
+      cb = 0;
+      ++tap;
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addresses: row r of a tile keeps its 16-byte chunks XORed with (r >> 1) & 7, which for the
+  // rows one lane reads (l15 + 16*i) is the same value for every i
+  const int l15 = lane & 15, q = lane >> 4, x = (l15 >> 1) & 7;
+  const int c0 = ((q ^ x) << 3), c1 = (((q ^ x) ^ 4) << 3);
+  const int aoff = (wm * 64 + l15) * BK, woff = BM * BK + (wn * 64 + l15) * BK;
+
+  auto compute = [&](const bf16* tile) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int cc = ks ? c1 : c0;
+      bf16x8 wf[4], af[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        wf[i] = *reinterpret_cast<const bf16x8*>(tile + woff + cc + i * 16 * BK);
+        af[i] = *reinterpret_cast<const bf16x8*>(tile + aoff + cc + i * 16 * BK);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  if (nk > 0) stage(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt += 2) {
+    if (kt + 1 < nk) stage(1);
+    compute(smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 >= nk) break;
+    if (kt + 2 < nk) stage(0);
+    compute(smem + (BM + BN) * BK);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
   }
+  nt_epilogue<MODE>(g, acc, m0, n0, wm, wn, lane, bias, out, relu, out_f32, beta);
 }
 
 // ----------------------------------------------------------------------------
@@ -669,13 +804,25 @@ bool use_glds() {
   return v != 0;
 }
 
+// VC_IGEMM_NT=generic keeps every layer on the general kernel (A/B measurements)
+bool use_generic_nt() {
+  static const int v = [] {
+    const char* e = getenv("VC_IGEMM_NT");
+    return (e && strcmp(e, "generic") == 0) ? 1 : 0;
+  }();
+  return v != 0;
+}
+
 template <int MODE>
 int launch_nt(const ConvGeom& g, int dtype, const void* src, const void* wgt, const float* bias, void* out, int relu,
               int out_f32, int beta, hipStream_t stream, const char* who) {
   if (dtype == VC_BF16) {
     VC_CHECK_SHAPE(g.Ci % 8 == 0, "%s: bf16 path needs source channels %% 8 == 0 (got %d)", who, g.Ci);
     const int tiles = ceil_div(g.M, BM) * ceil_div(g.Co, BN);
-    if (use_glds())
+    if (use_glds() && g.Ci % BK == 0 && g.ldi % 8 == 0 && !use_generic_nt())
+      hipLaunchKernelGGL((igemm_nt_fast_kernel<MODE>), dim3(tiles), dim3(NTHR), 0, stream, g, (const bf16*)src,
+                         (const bf16*)wgt, bias, out, relu, out_f32, beta);
+    else if (use_glds())
       hipLaunchKernelGGL((igemm_nt_bf16_kernel<MODE, true>), dim3(tiles), dim3(NTHR), 0, stream, g, (const bf16*)src,
                          (const bf16*)wgt, bias, out, relu, out_f32, beta);
     else
