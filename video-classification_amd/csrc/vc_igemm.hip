@@ -646,6 +646,171 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_tn_wgrad_bf16_kernel(ConvGeom g
   }
 }
 
+// Weight-gradient kernel with the per-row index arithmetic taken out of the staging loop: the 64 pixel rows
+// of a k-tile are decoded ONCE (by 64 threads, one tile ahead, into a small LDS table) instead of by every
+// thread that stages a piece of them, dy pointers advance by a constant per tile, and the transposing
+// fragment reads use per-lane offsets computed before the loop plus immediates.
+struct RowInfo {
+  int off;         // element offset of the row's window origin (tap 0,0,0) in x; may be negative
+  int d0, h0, w0;  // window origin coordinates; h0 = -2^28 marks a row beyond the split
+};
+
+__global__ __launch_bounds__(NTHR, 2) void igemm_tn_wgrad_fast_kernel(ConvGeom g, const bf16* __restrict__ x,
+                                                                      const bf16* __restrict__ dy, int ldy,
+                                                                      float* __restrict__ dw, int m_per_split,
+                                                                      int ntiles, int tiles_col) {
+  __shared__ __attribute__((aligned(1024))) bf16 smem[2 * 2 * BK * 128];
+  __shared__ __attribute__((aligned(16))) RowInfo rinfo[2][BK];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave >> 1, wm = wave & 1;  // wn: co half, wm: col half
+  int logical;
+  xcd_remap(logical);
+  const int split = logical / ntiles, tile = logical - split * ntiles;
+  const int tile_co = tile / tiles_col, tile_col = tile - tile_co * tiles_col;
+  const int co0 = tile_co * 128, col0 = tile_col * 128;
+  const int m_begin = split * m_per_split;
+  const int m_end = min(g.M, m_begin + m_per_split);
+  const bf16* zero = reinterpret_cast<const bf16*>(vc_zero_src);
+
+  const int pchunk = tid & 15, lrow = tid >> 4;
+  const int lchunk = ((((pchunk >> 1) ^ tn_swz(lrow)) << 1) | (pchunk & 1));
+  // this thread's gather column (tap, channel chunk) is fixed for the whole kernel
+  const int col = col0 + lchunk * 8;
+  const bool colvalid = col < g.K;
+  int rd, rh, rw, c;
+  decode_chunk(g, col >> 3, rd, rh, rw, c);
+  const int tapoff = ((rd * g.Hi + rh) * g.Wi + rw) * g.ldi + c;
+  const int co_ld = co0 + lchunk * 8;
+  const bool covalid = co_ld < g.Co;
+
+  auto decode_rows = [&](int mt, int slot, int t) {  // t in [0, BK): one row per calling thread
+    const int m = mt + t;
+    RowInfo ri;
+    ri.off = 0;
+    ri.d0 = ri.w0 = 0;
+    ri.h0 = -(1 << 28);
+    if (m < m_end) {
+      const RowPos rp = decode_row<0>(g, m);
+      ri.d0 = rp.d0;
+      ri.h0 = rp.h0;
+      ri.w0 = rp.w0;
+      ri.off = (((rp.n * g.Di + rp.d0) * g.Hi + rp.h0) * g.Wi + rp.w0) * g.ldi;
+    }
+    rinfo[slot][t] = ri;
+  };
+
+  const bf16* yp[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) yp[i] = dy + (size_t)(m_begin + lrow + 16 * i) * ldy + co_ld;
+  const int yinc = BK * ldy;
+
+  auto stage = [&](int mt, int buf) {
+    bf16* sY = smem + buf * (2 * BK * 128);
+    bf16* sX = sY + BK * 128;
+    int4 ri[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ri[i] = *reinterpret_cast<const int4*>(&rinfo[buf][lrow + 16 * i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      // branch-free: every test is evaluated, the pointers are selected
+      const int mvalid = (mt + lrow + 16 * i < m_end) & (int)covalid;
+      const int xok = (int)colvalid & (int)((unsigned)(ri[i].y + rd) < (unsigned)g.Di) &
+                      (int)((unsigned)(ri[i].z + rh) < (unsigned)g.Hi) &
+                      (int)((unsigned)(ri[i].w + rw) < (unsigned)g.Wi);
+      const int xo = xok ? ri[i].x + tapoff : 0;
+      const bf16* xsrc = xok ? x + xo : zero;
+      const bf16* ysrc = mvalid ? yp[i] : zero;
+      glds16(ysrc, sY + (16 * i + 4 * wave) * 128);
+      glds16(xsrc, sX + (16 * i + 4 * wave) * 128);
+      yp[i] += yinc;
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // transposing fragment reads: lane (gq, q, p) reads rows 8*gq + q (+4) (+32*ks) of a 16-column block;
+  // the row's block swizzle (row & 3) | ((row >> 1) & 4) is the same for all of them
+  const int gq = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  const int swz = q | ((gq & 1) << 2);
+  const int rbase = (8 * gq + q) * 128 + p * 4;
+  int yo[4], xo[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    yo[i] = rbase + (((wn * 4 + i) ^ swz) << 4);
+    xo[i] = BK * 128 + rbase + (((wm * 4 + i) ^ swz) << 4);
+  }
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  auto frag = [&](const bf16* tile, int off) {
+    union {
+      struct {
+        s16x4 a, b;
+      } s;
+      bf16x8 v;
+    } u;
+    u.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + off));
+    u.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + off + 4 * 128));
+    return u.v;
+  };
+  auto compute = [&](const bf16* tile) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 yf[4], xf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        yf[i] = frag(tile, yo[i] + ks * 32 * 128);
+        xf[i] = frag(tile, xo[i] + ks * 32 * 128);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // row tables of the first two tiles, then tile 0
+  if (tid < 2 * BK) decode_rows(m_begin + (tid >> 6) * BK, tid >> 6, tid & 63);
+  __syncthreads();
+  if (m_begin < m_end) stage(m_begin, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int mt = m_begin; mt < m_end; mt += 2 * BK) {
+    // tile mt in buffer 0
+    if (mt + BK < m_end) stage(mt + BK, 1);
+    if (tid < BK) decode_rows(mt + 2 * BK, 0, tid);  // table slot 0 was last read when tile mt was staged
+    compute(smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (mt + BK >= m_end) break;
+    // tile mt + BK in buffer 1
+    if (mt + 2 * BK < m_end) stage(mt + 2 * BK, 0);
+    if (tid < BK) decode_rows(mt + 3 * BK, 1, tid);
+    compute(smem + 2 * BK * 128);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = co0 + wn * 64 + i * 16 + (lane >> 4) * 4 + r;
+      if (co >= g.Co) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int cc = col0 + wm * 64 + j * 16 + (lane & 15);
+        if (cc < g.K) atomicAdd(dw + (size_t)co * g.K + cc, acc[i][j][r]);
+      }
+    }
+  }
+}
+
 // ----------------------------------------------------------------------------
 // Naive kernels (fp32 path and cross-check).
 // ----------------------------------------------------------------------------
@@ -813,6 +978,16 @@ bool use_generic_nt() {
   return v != 0;
 }
 
+// number of blocks the weight-gradient launch aims for (VC_WGRAD_BLOCKS overrides, for tuning runs)
+int wgrad_target_blocks() {
+  static const int v = [] {
+    const char* e = getenv("VC_WGRAD_BLOCKS");
+    const int n = e ? atoi(e) : 0;
+    return n > 0 ? n : 1024;
+  }();
+  return v;
+}
+
 template <int MODE>
 int launch_nt(const ConvGeom& g, int dtype, const void* src, const void* wgt, const float* bias, void* out, int relu,
               int out_f32, int beta, hipStream_t stream, const char* who) {
@@ -914,13 +1089,16 @@ int vc_conv_wgrad(const int* desc, int dtype, const void* x, int ldx, const void
     VC_CHECK_SHAPE(g.Ci % 8 == 0 && g.Co % 8 == 0, "vc_conv_wgrad: bf16 path needs Ci %% 8 == 0 and Co %% 8 == 0");
     const int tiles_co = ceil_div(g.Co, 128), tiles_col = ceil_div(g.K, 128);
     const int ntiles = tiles_co * tiles_col;
-    int splits = ceil_div(1024, ntiles);
+    int splits = ceil_div(wgrad_target_blocks(), ntiles);
     const int max_splits = ceil_div(g.M, BK);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     int mps = ceil_div(ceil_div(g.M, splits), BK) * BK;
     splits = ceil_div(g.M, mps);
-    if (use_glds())
+    if (use_glds() && !use_generic_nt())
+      hipLaunchKernelGGL(igemm_tn_wgrad_fast_kernel, dim3(ntiles * splits), dim3(NTHR), 0, stream, g, (const bf16*)x,
+                         (const bf16*)dy, ldy_, dw_packed, mps, ntiles, tiles_col);
+    else if (use_glds())
       hipLaunchKernelGGL((igemm_tn_wgrad_bf16_kernel<true>), dim3(ntiles * splits), dim3(NTHR), 0, stream, g,
                          (const bf16*)x, (const bf16*)dy, ldy_, dw_packed, mps, ntiles, tiles_col);
     else
