@@ -7,6 +7,8 @@
 // momentum updates per forward, in time order.  Frames are laid out time-major here
 // (frame = t*B + b), so a group is a contiguous block of `rpg` rows and G = T.
 // Conv3D / plain batches use G = 1.
+#include <stdlib.h>
+
 #include "vc_common.h"
 
 namespace {
@@ -122,25 +124,29 @@ __global__ void bn_reduce_kernel(const T* __restrict__ y, const T* __restrict__ 
         }
       }
     }
-    // reduce over the row lanes through LDS
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      red[0][tid][i] = a1[i];
-      red[1][tid][i] = a2[i];
-    }
-    __syncthreads();
-    if (rl == 0 && cvalid) {
-      for (int k = 1; k < RL; ++k) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          a1[i] += red[0][k * lanesC + cl][i];
-          a2[i] += red[1][k * lanesC + cl][i];
-        }
-      }
+    // reduce over the row lanes through LDS (channel-contiguous image), then ONE coalesced atomic per
+    // (statistic, channel): lane t adds channel cc0*8 + t
+    const int CB = lanesC * 8;  // channels covered by this sweep
+    float* r1 = &red[0][0][0];
+    float* r2 = r1 + NTHR * 8;
+    if (rl < RL) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        atomicAdd(s1 + g * C + cc * 8 + i, a1[i]);
-        atomicAdd(s2 + g * C + cc * 8 + i, a2[i]);
+        r1[rl * CB + cl * 8 + i] = a1[i];
+        r2[rl * CB + cl * 8 + i] = a2[i];
+      }
+    }
+    __syncthreads();
+    for (int ch = tid; ch < CB; ch += NTHR) {
+      const int cg = cc0 * 8 + ch;
+      if (cg < C) {
+        float t1 = 0.f, t2 = 0.f;
+        for (int k = 0; k < RL; ++k) {
+          t1 += r1[k * CB + ch];
+          t2 += r2[k * CB + ch];
+        }
+        atomicAdd(s1 + g * C + cg, t1);
+        atomicAdd(s2 + g * C + cg, t2);
       }
     }
     __syncthreads();
@@ -466,13 +472,24 @@ __global__ void ln_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dou
   }
 }
 
+inline int bn_reduce_blocks() {
+  static const int v = [] {
+    const char* e = getenv("VC_BN_REDUCE_BLOCKS");
+    const int n = e ? atoi(e) : 0;
+    return n > 0 ? n : 512;
+  }();
+  return v;
+}
+
 template <typename T, int MODE>
 int launch_reduce(const void* y, const void* dout, const void* act, const float* mean, const float* invstd,
                   const float* scale, const float* shift, float* s1, float* s2, int G, int rpg, int C, int relu,
                   hipStream_t stream) {
-  int rows_per_block = 256;
-  // enough blocks to fill the chip, few enough that the atomics stay cheap
-  while (rows_per_block < rpg && (int64_t)ceil_div(rpg, rows_per_block) * G > 2048) rows_per_block *= 2;
+  // about four blocks per CU: enough loads in flight to stream at HBM rate, few enough that the atomics
+  // that combine the blocks stay cheap; at least 16 rows per thread
+  const int C8 = C / 8, lanesC = C8 < NTHR ? C8 : NTHR, RL = NTHR / lanesC;
+  int rows_per_block = 16 * RL;
+  while (rows_per_block < rpg && (int64_t)ceil_div(rpg, rows_per_block) * G > bn_reduce_blocks()) rows_per_block *= 2;
   dim3 grid(ceil_div(rpg, rows_per_block), G);
   hipLaunchKernelGGL((bn_reduce_kernel<T, MODE>), grid, dim3(NTHR), 0, stream, (const T*)y, (const T*)dout,
                      (const T*)act, mean, invstd, scale, shift, s1, s2, C, rpg, rows_per_block, relu);
