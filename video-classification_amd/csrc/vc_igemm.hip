@@ -475,6 +475,231 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_fast_kernel(ConvGeom g, cons
   nt_epilogue<MODE>(g, acc, m0, n0, wm, wn, lane, bias, out, relu, out_f32, beta);
 }
 
+// Epilogue through LDS for compute-type (bf16) outputs: the wave parks its 64x64 sub-tile in an XOR-swizzled
+// LDS image and writes it out row-major, 16 bytes per lane, so that every store instruction covers whole
+// 128-byte row segments (the accumulator layout alone gives 32-byte pieces of 16 different rows).
+// `stage_buf` is this wave's private 8 KB region; the caller has made sure nobody still reads it.
+template <int MODE>
+__device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[4][4], int m0, int n0, int wm,
+                                                int wn, int lane, const float* __restrict__ bias,
+                                                bf16* __restrict__ out, int relu, int beta, bf16* stage_buf) {
+  const int l15 = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int col = i * 16 + q * 4;  // channel inside the wave's 64
+    float b[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias) {
+      const int co = n0 + wn * 64 + col;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (co + r < g.Co) b[r] = bias[co + r];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = j * 16 + l15;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[i][j][r] + b[r];
+        if (relu && !beta) v[r] = fmaxf(v[r], 0.f);
+      }
+      const int chunk = (col >> 3) ^ (row & 7);
+      *reinterpret_cast<bf16x4*>(stage_buf + row * 64 + chunk * 8 + (col & 7)) =
+          bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+    }
+  }
+  // the image is private to the wave: its own LDS writes complete before its reads (lgkmcnt order)
+  const int rr = lane >> 3, ch = lane & 7;
+  const int co = n0 + wn * 64 + ch * 8;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int row = it * 8 + rr;
+    const int m = m0 + wm * 64 + row;
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(stage_buf + row * 64 + ((ch ^ (row & 7)) << 3));
+    if (m < g.M && co < g.Co) {
+      bf16* op = out + (size_t)(MODE == 2 ? phase_out_pixel(g, m) : m) * g.ldc + co;
+      if (co + 7 < g.Co && (g.ldc & 7) == 0) {
+        if (beta) {
+          const bf16x8 old = *reinterpret_cast<const bf16x8*>(op);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float t = (float)v[e] + (float)old[e];
+            if (relu) t = fmaxf(t, 0.f);
+            v[e] = (bf16)t;
+          }
+        }
+        *reinterpret_cast<bf16x8*>(op) = v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (co + e < g.Co) {
+            float t = (float)v[e];
+            if (beta) {
+              t += (float)op[e];
+              if (relu) t = fmaxf(t, 0.f);
+            }
+            op[e] = (bf16)t;
+          }
+      }
+    }
+  }
+}
+
+// Persistent form of the fast NT kernel: a block walks output tiles v, v + G, v + 2G, ... and its staging
+// pipeline runs straight through the tile boundaries, so the first k-tile of the next output tile is already
+// streaming in while the epilogue of the current one is written.  Layers with a short reduction (1x1
+// convolutions with 64..256 channels are 1..4 k-tiles deep) otherwise pay a full memory latency per block.
+template <int MODE>
+__global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, const bf16* __restrict__ src,
+                                                                   const bf16* __restrict__ wgt,
+                                                                   const float* __restrict__ bias,
+                                                                   void* __restrict__ out, int relu, int out_f32,
+                                                                   int beta, int ntiles) {
+  __shared__ __attribute__((aligned(1024))) bf16 smem[2 * (BM + BN) * BK];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = (g.Co + BN - 1) / BN;
+  int vblock;
+  xcd_remap(vblock);
+  const int G = gridDim.x;
+
+  const int lrow = tid >> 3, pchunk = tid & 7;
+  const int lchunk = pchunk ^ ((lrow >> 1) & 7);
+  const int ncb = g.Ci / BK;  // k-tiles per tap
+  const int nk = g.K / BK;    // k-tiles per output tile (>= 1)
+  const bf16* zero = reinterpret_cast<const bf16*>(vc_zero_src);
+
+  // staging state (runs one k-tile ahead of the multiply)
+  int s_tile = vblock, s_kt = 0, tap = 0, cb = 0;
+  RowPos rp[4];
+  const bf16* ap[4];
+  const bf16* wp[4];
+  int ainc[4], winc[4];
+
+  auto stage = [&](int buf) {
+    const int tile_m = s_tile / tiles_n, tile_n = s_tile - tile_m * tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    if (s_kt == 0) {  // first k-tile of an output tile: its rows and weight rows
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        rp[i] = decode_row<MODE>(g, m0 + lrow + 32 * i);
+        const int co = n0 + lrow + 32 * i;
+        const bool ok = co < g.Co;
+        wp[i] = ok ? wgt + (size_t)co * g.ldw + lchunk * 8 : zero;
+        winc[i] = ok ? BK : 0;
+      }
+      tap = 0;
+      cb = 0;
+    }
+    if (cb == 0) {
+      int t2, rd, rh, rw;
+      fd_divmod(tap, g.fkw, t2, rw);
+      fd_divmod(t2, g.fkh, rd, rh);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int pix = gather_pixel<MODE>(g, rp[i], rd, rh, rw);
+        const bool ok = pix >= 0;
+        ap[i] = ok ? src + (size_t)pix * g.ldi + lchunk * 8 : zero;
+        ainc[i] = ok ? BK : 0;
+      }
+      if (MODE == 2) {
+        const int wcol = ((rd * g.wt_kh + g.wt_h0 + g.wt_hs * rh) * g.wt_kw + g.wt_w0 + g.wt_ws * rw) * g.Ci;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int co = n0 + lrow + 32 * i;
+          if (co < g.Co) wp[i] = wgt + (size_t)co * g.ldw + wcol + lchunk * 8;
+        }
+      }
+    }
+    bf16* sA = smem + buf * (BM + BN) * BK;
+    bf16* sW = sA + BM * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16(ap[i], sA + (32 * i + 8 * wave) * BK);
+      glds16(wp[i], sW + (32 * i + 8 * wave) * BK);
+      ap[i] += ainc[i];
+      wp[i] += winc[i];
+    }
+    if (++cb == ncb) {
+      cb = 0;
+      ++tap;
+    }
+    if (++s_kt == nk) {
+      s_kt = 0;
+      s_tile += G;
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int l15 = lane & 15, q = lane >> 4, x = (l15 >> 1) & 7;
+  const int c0 = ((q ^ x) << 3), c1 = (((q ^ x) ^ 4) << 3);
+  const int aoff = (wm * 64 + l15) * BK, woff = BM * BK + (wn * 64 + l15) * BK;
+
+  auto compute = [&](const bf16* tile) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int cc = ks ? c1 : c0;
+      bf16x8 wf[4], af[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        wf[i] = *reinterpret_cast<const bf16x8*>(tile + woff + cc + i * 16 * BK);
+        af[i] = *reinterpret_cast<const bf16x8*>(tile + aoff + cc + i * 16 * BK);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // multiply state
+  int c_tile = vblock, c_kt = 0;
+  auto finish_ktile = [&](bf16* cbuf) {
+    if (++c_kt == nk) {  // output tile complete
+      const int tile_m = c_tile / tiles_n, tile_n = c_tile - tile_m * tiles_n;
+      if (out_f32) {
+        nt_epilogue<MODE>(g, acc, tile_m * BM, tile_n * BN, wm, wn, lane, bias, out, relu, out_f32, beta);
+      } else {
+        // the buffer that was just multiplied is free once every wave has finished reading it
+        __syncthreads();
+        nt_epilogue_lds<MODE>(g, acc, tile_m * BM, tile_n * BN, wm, wn, lane, bias, reinterpret_cast<bf16*>(out),
+                              relu, beta, cbuf + wave * (64 * 64));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      c_kt = 0;
+      c_tile += G;
+    }
+  };
+
+  if (vblock < ntiles) stage(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  while (c_tile < ntiles) {
+    if (s_tile < ntiles) stage(1);
+    compute(smem);
+    finish_ktile(smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (c_tile >= ntiles) break;
+    if (s_tile < ntiles) stage(0);
+    compute(smem + (BM + BN) * BK);
+    finish_ktile(smem + (BM + BN) * BK);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+}
+
 // ----------------------------------------------------------------------------
 // TN kernel (weight gradient).  g is the FORWARD geometry (src = x).
 // ----------------------------------------------------------------------------
@@ -969,6 +1194,25 @@ bool use_glds() {
   return v != 0;
 }
 
+// VC_IGEMM_NT = generic | fast | persist selects the NT kernel family (A/B measurements); default persist
+int nt_variant() {
+  static const int v = [] {
+    const char* e = getenv("VC_IGEMM_NT");
+    if (e && strcmp(e, "generic") == 0) return 0;
+    if (e && strcmp(e, "fast") == 0) return 1;
+    return 2;
+  }();
+  return v;
+}
+int nt_persist_blocks() {
+  static const int v = [] {
+    const char* e = getenv("VC_NT_BLOCKS");
+    const int n = e ? atoi(e) : 0;
+    return n > 0 ? n : 512;
+  }();
+  return v;
+}
+
 // VC_IGEMM_NT=generic keeps every layer on the general kernel (A/B measurements)
 bool use_generic_nt() {
   static const int v = [] {
@@ -994,7 +1238,11 @@ int launch_nt(const ConvGeom& g, int dtype, const void* src, const void* wgt, co
   if (dtype == VC_BF16) {
     VC_CHECK_SHAPE(g.Ci % 8 == 0, "%s: bf16 path needs source channels %% 8 == 0 (got %d)", who, g.Ci);
     const int tiles = ceil_div(g.M, BM) * ceil_div(g.Co, BN);
-    if (use_glds() && g.Ci % BK == 0 && g.ldi % 8 == 0 && !use_generic_nt())
+    if (use_glds() && g.Ci % BK == 0 && g.ldi % 8 == 0 && g.K >= BK && nt_variant() == 2) {
+      const int grid = tiles < nt_persist_blocks() ? tiles : nt_persist_blocks();
+      hipLaunchKernelGGL((igemm_nt_persist_kernel<MODE>), dim3(grid), dim3(NTHR), 0, stream, g, (const bf16*)src,
+                         (const bf16*)wgt, bias, out, relu, out_f32, beta, tiles);
+    } else if (use_glds() && g.Ci % BK == 0 && g.ldi % 8 == 0 && nt_variant() >= 1)
       hipLaunchKernelGGL((igemm_nt_fast_kernel<MODE>), dim3(tiles), dim3(NTHR), 0, stream, g, (const bf16*)src,
                          (const bf16*)wgt, bias, out, relu, out_f32, beta);
     else if (use_glds())
