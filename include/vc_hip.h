@@ -62,7 +62,9 @@ int vc_pack_weight(int dtype, const float* w, void* w_fwd, void* w_t, int co, in
  * layer over the flattened channels-last map (EncoderCNN.fc1 after x.view(B,-1), model_components.py:131-134) */
 int vc_pack_weight_flat_t(int dtype, const float* w, void* w_t, int co, int ci, int taps, int ci_pad, int co_pad,
                           vc_stream_t stream);
-int vc_unpack_wgrad(const float* dw_packed, float* dw, int co, int ci, int taps, int ci_pad, int accumulate,
+/* flags: bit 0 = add to dw (gradient accumulation) instead of overwriting it; bit 1 = zero dw_packed after it has
+ * been read, so a caller-owned accumulator is ready for the next vc_conv_wgrad without a fill pass */
+int vc_unpack_wgrad(float* dw_packed, float* dw, int co, int ci, int taps, int ci_pad, int flags,
                     vc_stream_t stream);
 
 /* ---- BatchNorm with per-group statistics / LayerNorm ----------------------------------------------
@@ -72,9 +74,10 @@ int vc_unpack_wgrad(const float* dw_packed, float* dw, int co, int ci, int taps,
  * per-time-step statistics and its T ordered running-stat updates (encoder loops at :119, :174, :281).
  * sum/sumsq/s1/s2 are [G][C] fp32 accumulated with atomics: the caller zeroes them. */
 int vc_bn_stats(int dtype, const void* y, float* sum, float* sumsq, int G, int rpg, int C, vc_stream_t stream);
-int vc_bn_finalize(const float* sum, const float* sumsq, const float* gamma, const float* beta, float* running_mean,
+/* flags: bit 0 = apply the G ordered momentum updates to running_mean/var; bit 1 = zero sum/sumsq after reading */
+int vc_bn_finalize(float* sum, float* sumsq, const float* gamma, const float* beta, float* running_mean,
                    float* running_var, float* mean, float* invstd, float* scale, float* shift, int G, int C, int rpg,
-                   float eps, float momentum, int update_running, vc_stream_t stream);
+                   float eps, float momentum, int flags, vc_stream_t stream);
 int vc_bn_eval_params(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                       float* scale, float* shift, int C, float eps, vc_stream_t stream);
 int vc_bn_apply(int dtype, const void* y, const float* scale, const float* shift, const void* residual, void* out,
@@ -87,7 +90,9 @@ int vc_bn_bwd_reduce(int dtype, const void* y, const void* dout, const void* act
 int vc_bn_bwd_apply(int dtype, const void* y, const void* dout, const void* act, const float* mean,
                     const float* invstd, const float* scale, const float* shift, const float* s1, const float* s2,
                     void* dy, void* dres, int G, int rpg, int C, int relu, vc_stream_t stream);
-int vc_bn_bwd_params(const float* s1, const float* s2, float* dgamma, float* dbeta, int G, int C, int accumulate,
+/* flags: bit 0 = add to dgamma/dbeta instead of overwriting; bit 1 = zero s1/s2 after reading (dgamma and dbeta may
+ * both be NULL: the call then only clears) */
+int vc_bn_bwd_params(float* s1, float* s2, float* dgamma, float* dbeta, int G, int C, int flags,
                      vc_stream_t stream);
 /* nn.LayerNorm inside the Swin-T backbone (timm, created at model_components.py:254, 412) */
 int vc_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* out, float* mean,

@@ -1132,15 +1132,19 @@ __global__ void pack_weight_flat_t_kernel(const float* __restrict__ w, T* __rest
 }
 
 // packed fp32 gradient [Co][taps][Cip] -> torch layout [Co][Ci][taps] (accumulating or not)
-__global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Co, int Ci, int taps,
-                                    int Cip, int accumulate) {
+// flags: bit 0 = add to dw instead of overwriting it, bit 1 = zero the packed source after reading it (a
+// caller-owned accumulator is then ready for the next weight-gradient launch without a fill pass)
+__global__ void unpack_wgrad_kernel(float* __restrict__ dwp, float* __restrict__ dw, int Co, int Ci, int taps,
+                                    int Cip, int flags) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)Co * Ci * taps) return;
   const int tap = (int)(idx % taps);
   const int ci = (int)((idx / taps) % Ci);
   const int co = (int)(idx / ((int64_t)taps * Ci));
-  const float v = dwp[((size_t)co * taps + tap) * Cip + ci];
-  dw[idx] = accumulate ? dw[idx] + v : v;
+  const size_t src = ((size_t)co * taps + tap) * Cip + ci;
+  const float v = dwp[src];
+  if (flags & 2) dwp[src] = 0.f;
+  dw[idx] = (flags & 1) ? dw[idx] + v : v;
 }
 
 int fill_geom(ConvGeom& g, const int* d, int mode, const char* who) {
@@ -1424,12 +1428,12 @@ int vc_pack_weight_flat_t(int dtype, const float* w, void* w_t, int co, int ci, 
   return VC_OK;
 }
 
-int vc_unpack_wgrad(const float* dw_packed, float* dw, int co, int ci, int taps, int ci_pad, int accumulate,
+int vc_unpack_wgrad(float* dw_packed, float* dw, int co, int ci, int taps, int ci_pad, int flags,
                     hipStream_t stream) {
   VC_CHECK_ARG(dw_packed && dw, "vc_unpack_wgrad: null pointer");
   const int64_t total = (int64_t)co * ci * taps;
   hipLaunchKernelGGL(unpack_wgrad_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, stream, dw_packed, dw,
-                     co, ci, taps, ci_pad, accumulate);
+                     co, ci, taps, ci_pad, flags);
   VC_LAUNCH_CHECK("vc_unpack_wgrad");
   return VC_OK;
 }

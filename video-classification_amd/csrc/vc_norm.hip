@@ -153,14 +153,16 @@ __global__ void bn_reduce_kernel(const T* __restrict__ y, const T* __restrict__ 
   }
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ sum, const float* __restrict__ sumsq,
+// flags: bit 0 = update the running statistics, bit 1 = zero sum/sumsq after reading them
+__global__ void bn_finalize_kernel(float* __restrict__ sum, float* __restrict__ sumsq,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float* __restrict__ mean_out, float* __restrict__ invstd_out,
                                    float* __restrict__ scale, float* __restrict__ shift, int G, int C, float cnt,
-                                   float eps, float momentum, int update_running) {
+                                   float eps, float momentum, int flags) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
+  const int update_running = flags & 1;
   float rm = 0.f, rv = 0.f;
   if (update_running) {
     rm = running_mean[c];
@@ -170,6 +172,10 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sum, const float* _
   for (int g = 0; g < G; ++g) {
     const double m = (double)sum[g * C + c] / cnt;
     double var = (double)sumsq[g * C + c] / cnt - m * m;
+    if (flags & 2) {
+      sum[g * C + c] = 0.f;
+      sumsq[g * C + c] = 0.f;
+    }
     if (var < 0.0) var = 0.0;
     const float is = (float)(1.0 / sqrt(var + (double)eps));
     mean_out[g * C + c] = (float)m;
@@ -345,18 +351,22 @@ __global__ __launch_bounds__(NTHR) void bn_bwd_apply_kernel(
 }
 
 // dgamma[c] (+)= sum_g s2[g][c]; dbeta[c] (+)= sum_g s1[g][c]
-__global__ void bn_bwd_params_kernel(const float* __restrict__ s1, const float* __restrict__ s2,
-                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int G, int C,
-                                     int accumulate) {
+// flags: bit 0 = add to dgamma/dbeta instead of overwriting, bit 1 = zero s1/s2 after reading them
+__global__ void bn_bwd_params_kernel(float* __restrict__ s1, float* __restrict__ s2, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta, int G, int C, int flags) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   float a = 0.f, b = 0.f;
   for (int g = 0; g < G; ++g) {
     a += s2[g * C + c];
     b += s1[g * C + c];
+    if (flags & 2) {
+      s1[g * C + c] = 0.f;
+      s2[g * C + c] = 0.f;
+    }
   }
-  if (dgamma) dgamma[c] = accumulate ? dgamma[c] + a : a;
-  if (dbeta) dbeta[c] = accumulate ? dbeta[c] + b : b;
+  if (dgamma) dgamma[c] = (flags & 1) ? dgamma[c] + a : a;
+  if (dbeta) dbeta[c] = (flags & 1) ? dbeta[c] + b : b;
 }
 
 // ------------------------------ LayerNorm ---------------------------------
@@ -522,14 +532,13 @@ int vc_bn_stats(int dtype, const void* y, float* sum, float* sumsq, int G, int r
   return VC_OK;
 }
 
-int vc_bn_finalize(const float* sum, const float* sumsq, const float* gamma, const float* beta, float* running_mean,
+int vc_bn_finalize(float* sum, float* sumsq, const float* gamma, const float* beta, float* running_mean,
                    float* running_var, float* mean, float* invstd, float* scale, float* shift, int G, int C, int rpg,
-                   float eps, float momentum, int update_running, hipStream_t stream) {
+                   float eps, float momentum, int flags, hipStream_t stream) {
   VC_CHECK_ARG(sum && sumsq && mean && invstd && scale && shift, "vc_bn_finalize: null pointer");
-  VC_CHECK_ARG(!update_running || (running_mean && running_var), "vc_bn_finalize: running stats missing");
+  VC_CHECK_ARG(!(flags & 1) || (running_mean && running_var), "vc_bn_finalize: running stats missing");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, stream, sum, sumsq, gamma, beta,
-                     running_mean, running_var, mean, invstd, scale, shift, G, C, (float)rpg, eps, momentum,
-                     update_running);
+                     running_mean, running_var, mean, invstd, scale, shift, G, C, (float)rpg, eps, momentum, flags);
   VC_LAUNCH_CHECK("vc_bn_finalize");
   return VC_OK;
 }
@@ -599,11 +608,11 @@ int vc_bn_bwd_apply(int dtype, const void* y, const void* dout, const void* act,
   return VC_OK;
 }
 
-int vc_bn_bwd_params(const float* s1, const float* s2, float* dgamma, float* dbeta, int G, int C, int accumulate,
+int vc_bn_bwd_params(float* s1, float* s2, float* dgamma, float* dbeta, int G, int C, int flags,
                      hipStream_t stream) {
   VC_CHECK_ARG(s1 && s2, "vc_bn_bwd_params: null pointer");
   hipLaunchKernelGGL(bn_bwd_params_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, stream, s1, s2, dgamma, dbeta, G, C,
-                     accumulate);
+                     flags);
   VC_LAUNCH_CHECK("vc_bn_bwd_params");
   return VC_OK;
 }

@@ -151,6 +151,26 @@ def _packed_weights(weight, ci, taps, cip, cop, dtype):
     return wf, wt
 
 
+def _wgrad_scratch(weight, shape):
+    """fp32 accumulator of a packed weight gradient, owned by the parameter and kept ZERO between uses:
+    vc_unpack_wgrad clears it while it reads it, so no per-step fill pass is launched."""
+    buf = getattr(weight, "_vc_dwp", None)
+    if buf is None or tuple(buf.shape) != tuple(shape) or buf.device != weight.device:
+        buf = torch.zeros(shape, device=weight.device, dtype=torch.float32)
+        weight._vc_dwp = buf
+    return buf
+
+
+def _zero_scratch(owner, name, shape, device):
+    """Zero-initialised fp32 scratch cached on `owner` (a module); the kernels that consume it clear it again."""
+    buf = getattr(owner, name, None) if owner is not None else None
+    if buf is None or tuple(buf.shape) != tuple(shape) or buf.device != device:
+        buf = torch.zeros(shape, device=device, dtype=torch.float32)
+        if owner is not None:
+            object.__setattr__(owner, name, buf)
+    return buf
+
+
 class _Conv(torch.autograd.Function):
     """y = conv(x, weight) + bias (optionally ReLU) on channels-last tensors."""
 
@@ -216,10 +236,16 @@ class _Conv(torch.autograd.Function):
         desc = L.int_array(ctx.desc)
         weight, bias = ctx.weight, ctx.bias
         if weight.requires_grad:
-            dwp = torch.zeros(cop, ctx.taps, cip, device=x.device, dtype=torch.float32)
-            _timed("conv_wgrad", ctx.flops, lambda: L.call(
-                "vc_conv_wgrad", desc, code, L.ptr(x), 0, L.ptr(dy), 0, L.ptr(dwp), 0, L.stream()))
-            L.call("vc_unpack_wgrad", L.ptr(dwp), L.ptr(_grad_buf(weight)), co, ci, ctx.taps, cip, 1, L.stream())
+            if ctx.taps == 1 and cip == ci and cop == co:
+                # the packed layout IS the parameter's layout: accumulate straight into the gradient
+                dwp = _grad_buf(weight)
+                _timed("conv_wgrad", ctx.flops, lambda: L.call(
+                    "vc_conv_wgrad", desc, code, L.ptr(x), 0, L.ptr(dy), 0, L.ptr(dwp), 0, L.stream()))
+            else:
+                dwp = _wgrad_scratch(weight, (cop, ctx.taps, cip))
+                _timed("conv_wgrad", ctx.flops, lambda: L.call(
+                    "vc_conv_wgrad", desc, code, L.ptr(x), 0, L.ptr(dy), 0, L.ptr(dwp), 0, L.stream()))
+                L.call("vc_unpack_wgrad", L.ptr(dwp), L.ptr(_grad_buf(weight)), co, ci, ctx.taps, cip, 3, L.stream())
         if bias is not None and bias.requires_grad:
             M = dy.numel() // cop
             L.call("vc_colsum", code, L.ptr(dy), L.ptr(_grad_buf(bias)), M, co, cop, L.stream())
@@ -278,9 +304,10 @@ def linear(x, weight, bias=None, relu=False, out_f32=False):
 class _BatchNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, gamma, beta, running_mean, running_var, groups, momentum, eps, relu, residual, training,
-                res_join):
+                res_join, owner):
         _require_cuda(y, "batch_norm")
         ctx.res_join = res_join
+        ctx.owner = owner
         y = y.contiguous()
         C = y.shape[-1]
         M = y.numel() // C
@@ -293,13 +320,13 @@ class _BatchNorm(torch.autograd.Function):
             if M % G:
                 raise RuntimeError(f"batch_norm: {M} rows do not split into {G} groups")
             rpg = M // G
-            sums = torch.zeros(2, G, C, device=dev, dtype=torch.float32)
+            sums = _zero_scratch(owner, "_vc_sums", (2, G, C), dev)  # cleared again by vc_bn_finalize
             stat = torch.empty(4, G, C, device=dev, dtype=torch.float32)  # mean, invstd, scale, shift
             L.call("vc_bn_stats", code, L.ptr(y), L.ptr(sums[0]), L.ptr(sums[1]), G, rpg, C, L.stream())
             upd = running_mean is not None
             L.call("vc_bn_finalize", L.ptr(sums[0]), L.ptr(sums[1]), L.ptr(ga), L.ptr(be), L.ptr(running_mean),
                    L.ptr(running_var), L.ptr(stat[0]), L.ptr(stat[1]), L.ptr(stat[2]), L.ptr(stat[3]), G, C, rpg,
-                   float(eps), float(momentum), int(upd), L.stream())
+                   float(eps), float(momentum), int(upd) | 2, L.stream())
         else:
             G, rpg = 1, M
             stat = torch.empty(4, 1, C, device=dev, dtype=torch.float32)
@@ -324,7 +351,7 @@ class _BatchNorm(torch.autograd.Function):
         G, rpg, C = ctx.G, ctx.rpg, ctx.C
         code = L.dtype_code(y.dtype)
         dout = cast(dout.contiguous(), y.dtype)
-        s = torch.zeros(2, G, C, device=y.device, dtype=torch.float32)
+        s = _zero_scratch(ctx.owner, "_vc_bsums", (2, G, C), y.device)  # cleared again by vc_bn_bwd_params
         L.call("vc_bn_bwd_reduce", code, L.ptr(y), L.ptr(dout), L.ptr(out), L.ptr(stat[0]), L.ptr(stat[1]),
                L.ptr(stat[2]), L.ptr(stat[3]), L.ptr(s[0]), L.ptr(s[1]), G, rpg, C, int(ctx.relu), L.stream())
         dy = torch.empty_like(y)
@@ -339,10 +366,9 @@ class _BatchNorm(torch.autograd.Function):
             dres = join.arrive(dres)
         dg = _grad_buf(ctx.gamma) if ctx.gamma is not None and ctx.gamma.requires_grad else None
         db = _grad_buf(ctx.beta) if ctx.beta is not None and ctx.beta.requires_grad else None
-        if dg is not None or db is not None:
-            L.call("vc_bn_bwd_params", L.ptr(s[0]), L.ptr(s[1]), L.ptr(dg), L.ptr(db), G, C, 1, L.stream())
+        L.call("vc_bn_bwd_params", L.ptr(s[0]), L.ptr(s[1]), L.ptr(dg), L.ptr(db), G, C, 3, L.stream())
         _ready(ctx.gamma, ctx.beta)
-        return dy, None, None, None, None, None, None, None, None, dres, None, None
+        return dy, None, None, None, None, None, None, None, None, dres, None, None, None
 
 
 def batch_norm(y, bn, groups, relu=False, residual=None, res_join=None):
@@ -351,7 +377,7 @@ def batch_norm(y, bn, groups, relu=False, residual=None, res_join=None):
     training = bn.training or bn.running_mean is None
     out = _BatchNorm.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, groups,
                            bn.momentum if bn.momentum is not None else 0.1, bn.eps, relu, residual, training,
-                           res_join)
+                           res_join, bn)
     if training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked += groups
     return out
@@ -568,19 +594,16 @@ class _LSTM(torch.autograd.Function):
                     nxt = t
                 # weight gradients over the whole sequence
                 if w_ih.requires_grad:
-                    dwp = torch.zeros(4 * H, Kin, device=dev, dtype=f32)
+                    # a Linear weight's packed gradient layout is the parameter's own: accumulate in place
                     L.call("vc_conv_wgrad", _lin_desc(T * B, Kin, 4 * H), code, L.ptr(inp), 0, L.ptr(dg), 0,
-                           L.ptr(dwp), 0, st)
-                    L.call("vc_unpack_wgrad", L.ptr(dwp), L.ptr(_grad_buf(w_ih)), 4 * H, Kin, 1, Kin, 1, st)
+                           L.ptr(_grad_buf(w_ih)), 0, st)
                 if w_hh.requires_grad and T > 1:
-                    dwp = torch.zeros(4 * H, H, device=dev, dtype=f32)
                     # pairs (h_prev, dgates_t): forward dir h[0..T-2] with dg[1..T-1]; reverse dir h[1..T-1] with dg[0..T-2]
                     h_off = 0 if d == 0 else 1
                     g_off = 1 if d == 0 else 0
                     L.call("vc_conv_wgrad", _lin_desc((T - 1) * B, H, 4 * H), code,
                            _off(out, (h_off * B) * H * dirs + d * H), H * dirs, _off(dg, g_off * B * 4 * H), 0,
-                           L.ptr(dwp), 0, st)
-                    L.call("vc_unpack_wgrad", L.ptr(dwp), L.ptr(_grad_buf(w_hh)), 4 * H, H, 1, H, 1, st)
+                           L.ptr(_grad_buf(w_hh)), 0, st)
                 for b_ in (b_ih, b_hh):
                     if b_.requires_grad:
                         L.call("vc_colsum", code, L.ptr(dg), L.ptr(_grad_buf(b_)), T * B, 4 * H, 4 * H, st)
@@ -825,9 +848,7 @@ class _TCGFuse(torch.autograd.Function):
         desc = _lin_desc(T * B, 4 * H, 2 * H)
         gw, gb = ctx.gate_w, ctx.gate_b
         if gw.requires_grad:
-            dwp = torch.zeros(2 * H, 4 * H, device=dev, dtype=torch.float32)
-            L.call("vc_conv_wgrad", desc, code, L.ptr(cat), 0, L.ptr(dz), 0, L.ptr(dwp), 0, st)
-            L.call("vc_unpack_wgrad", L.ptr(dwp), L.ptr(_grad_buf(gw)), 2 * H, 4 * H, 1, 4 * H, 1, st)
+            L.call("vc_conv_wgrad", desc, code, L.ptr(cat), 0, L.ptr(dz), 0, L.ptr(_grad_buf(gw)), 0, st)
         if gb.requires_grad:
             L.call("vc_colsum", code, L.ptr(dz), L.ptr(_grad_buf(gb)), T * B, 2 * H, 2 * H, st)
         _ready(gw, gb)
