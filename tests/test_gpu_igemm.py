@@ -25,6 +25,10 @@ CASES = [
     ("c2d_7x7_s2_p3", 2, 1, 32, 32, 8, 64, (1, 7, 7), (1, 2, 2), (0, 3, 3)),
     ("c2d_3x3_s2_p1", 2, 1, 28, 28, 128, 128, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
     ("c2d_wide", 4, 1, 14, 14, 256, 264, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("c2d_3x3_64_64", 3, 1, 14, 13, 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("c2d_1x1_256_64", 2, 1, 9, 11, 256, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("c2d_1x1_64_256", 5, 1, 12, 12, 64, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("c2d_3x3_s2_64_40", 2, 1, 17, 17, 64, 40, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
     ("c3d_3x3x3_p1", 2, 4, 10, 9, 8, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     ("c3d_3x3x3_p1_b", 1, 5, 7, 12, 32, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
 ]

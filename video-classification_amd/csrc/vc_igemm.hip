@@ -143,8 +143,8 @@ __device__ __forceinline__ void glds16(const void* g, bf16* lds_wave_base) {
 }
 
 // Epilogue shared by the NT kernels: a lane holds 4 consecutive channels of one pixel per 16x16 tile.
-template <int MODE>
-__device__ __forceinline__ void nt_epilogue(const ConvGeom& g, f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn,
+template <int MODE, int WI = 4>
+__device__ __forceinline__ void nt_epilogue(const ConvGeom& g, f32x4 (&acc)[WI][4], int m0, int n0, int wm, int wn,
                                             int lane, const float* __restrict__ bias, void* __restrict__ out,
                                             int relu, int out_f32, int beta) {
 #pragma unroll
@@ -152,8 +152,8 @@ __device__ __forceinline__ void nt_epilogue(const ConvGeom& g, f32x4 (&acc)[4][4
     const int m = m0 + wm * 64 + j * 16 + (lane & 15);
     if (m >= g.M) continue;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int co = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
+    for (int i = 0; i < WI; ++i) {
+      const int co = n0 + wn * (WI * 16) + i * 16 + (lane >> 4) * 4;
       if (co >= g.Co) continue;
       float v[4];
 #pragma unroll
@@ -479,17 +479,19 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_fast_kernel(ConvGeom g, cons
 // LDS image and writes it out row-major, 16 bytes per lane, so that every store instruction covers whole
 // 128-byte row segments (the accumulator layout alone gives 32-byte pieces of 16 different rows).
 // `stage_buf` is this wave's private 8 KB region; the caller has made sure nobody still reads it.
-template <int MODE>
-__device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[4][4], int m0, int n0, int wm,
+template <int MODE, int WI>
+__device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[WI][4], int m0, int n0, int wm,
                                                 int wn, int lane, const float* __restrict__ bias,
                                                 bf16* __restrict__ out, int relu, int beta, bf16* stage_buf) {
+  constexpr int WC = WI * 16;   // channels per wave (64 or 32)
+  constexpr int NCH = WC / 8;   // 16-byte chunks per image row (8 or 4)
   const int l15 = lane & 15, q = lane >> 4;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int col = i * 16 + q * 4;  // channel inside the wave's 64
+  for (int i = 0; i < WI; ++i) {
+    const int col = i * 16 + q * 4;  // channel inside the wave's WC
     float b[4] = {0.f, 0.f, 0.f, 0.f};
     if (bias) {
-      const int co = n0 + wn * 64 + col;
+      const int co = n0 + wn * WC + col;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (co + r < g.Co) b[r] = bias[co + r];
@@ -503,19 +505,20 @@ __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[
         v[r] = acc[i][j][r] + b[r];
         if (relu && !beta) v[r] = fmaxf(v[r], 0.f);
       }
-      const int chunk = (col >> 3) ^ (row & 7);
-      *reinterpret_cast<bf16x4*>(stage_buf + row * 64 + chunk * 8 + (col & 7)) =
+      const int chunk = (col >> 3) ^ (row & (NCH - 1));
+      *reinterpret_cast<bf16x4*>(stage_buf + row * WC + chunk * 8 + (col & 7)) =
           bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
     }
   }
   // the image is private to the wave: its own LDS writes complete before its reads (lgkmcnt order)
-  const int rr = lane >> 3, ch = lane & 7;
-  const int co = n0 + wn * 64 + ch * 8;
+  constexpr int RPI = 64 / NCH;  // image rows per store instruction (8 or 16)
+  const int rr = lane / NCH, ch = lane % NCH;
+  const int co = n0 + wn * WC + ch * 8;
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int row = it * 8 + rr;
+  for (int it = 0; it < 64 / RPI; ++it) {
+    const int row = it * RPI + rr;
     const int m = m0 + wm * 64 + row;
-    bf16x8 v = *reinterpret_cast<const bf16x8*>(stage_buf + row * 64 + ((ch ^ (row & 7)) << 3));
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(stage_buf + row * WC + ((ch ^ (row & (NCH - 1))) << 3));
     if (m < g.M && co < g.Co) {
       bf16* op = out + (size_t)(MODE == 2 ? phase_out_pixel(g, m) : m) * g.ldc + co;
       if (co + 7 < g.Co && (g.ldc & 7) == 0) {
@@ -549,18 +552,20 @@ __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[
 // pipeline runs straight through the tile boundaries, so the first k-tile of the next output tile is already
 // streaming in while the epilogue of the current one is written.  Layers with a short reduction (1x1
 // convolutions with 64..256 channels are 1..4 k-tiles deep) otherwise pay a full memory latency per block.
-template <int MODE>
+template <int MODE, int TN_>
 __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, const bf16* __restrict__ src,
                                                                    const bf16* __restrict__ wgt,
                                                                    const float* __restrict__ bias,
                                                                    void* __restrict__ out, int relu, int out_f32,
                                                                    int beta, int ntiles) {
-  __shared__ __attribute__((aligned(1024))) bf16 smem[2 * (BM + BN) * BK];
+  __shared__ __attribute__((aligned(1024))) bf16 smem[2 * (BM + TN_) * BK];
+  constexpr int WI = TN_ / 32;   // 16-channel tiles per wave
+  constexpr int NWROW = TN_ / 32;  // weight rows staged per thread
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int tiles_n = (g.Co + BN - 1) / BN;
+  const int tiles_n = (g.Co + TN_ - 1) / TN_;
   int vblock;
   xcd_remap(vblock);
   const int G = gridDim.x;
@@ -580,11 +585,12 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
 
   auto stage = [&](int buf) {
     const int tile_m = s_tile / tiles_n, tile_n = s_tile - tile_m * tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int m0 = tile_m * BM, n0 = tile_n * TN_;
     if (s_kt == 0) {  // first k-tile of an output tile: its rows and weight rows
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        rp[i] = decode_row<MODE>(g, m0 + lrow + 32 * i);
+      for (int i = 0; i < 4; ++i) rp[i] = decode_row<MODE>(g, m0 + lrow + 32 * i);
+#pragma unroll
+      for (int i = 0; i < NWROW; ++i) {
         const int co = n0 + lrow + 32 * i;
         const bool ok = co < g.Co;
         wp[i] = ok ? wgt + (size_t)co * g.ldw + lchunk * 8 : zero;
@@ -607,19 +613,22 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
       if (MODE == 2) {
         const int wcol = ((rd * g.wt_kh + g.wt_h0 + g.wt_hs * rh) * g.wt_kw + g.wt_w0 + g.wt_ws * rw) * g.Ci;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NWROW; ++i) {
           const int co = n0 + lrow + 32 * i;
           if (co < g.Co) wp[i] = wgt + (size_t)co * g.ldw + wcol + lchunk * 8;
         }
       }
     }
-    bf16* sA = smem + buf * (BM + BN) * BK;
+    bf16* sA = smem + buf * (BM + TN_) * BK;
     bf16* sW = sA + BM * BK;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       glds16(ap[i], sA + (32 * i + 8 * wave) * BK);
-      glds16(wp[i], sW + (32 * i + 8 * wave) * BK);
       ap[i] += ainc[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NWROW; ++i) {
+      glds16(wp[i], sW + (32 * i + 8 * wave) * BK);
       wp[i] += winc[i];
     }
     if (++cb == ncb) {
@@ -632,28 +641,27 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
     }
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[WI][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < WI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int l15 = lane & 15, q = lane >> 4, x = (l15 >> 1) & 7;
   const int c0 = ((q ^ x) << 3), c1 = (((q ^ x) ^ 4) << 3);
-  const int aoff = (wm * 64 + l15) * BK, woff = BM * BK + (wn * 64 + l15) * BK;
+  const int aoff = (wm * 64 + l15) * BK, woff = BM * BK + (wn * (WI * 16) + l15) * BK;
 
   auto compute = [&](const bf16* tile) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int cc = ks ? c1 : c0;
-      bf16x8 wf[4], af[4];
+      bf16x8 wf[WI], af[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        wf[i] = *reinterpret_cast<const bf16x8*>(tile + woff + cc + i * 16 * BK);
-        af[i] = *reinterpret_cast<const bf16x8*>(tile + aoff + cc + i * 16 * BK);
-      }
+      for (int i = 0; i < WI; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(tile + woff + cc + i * 16 * BK);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(tile + aoff + cc + i * 16 * BK);
+#pragma unroll
+      for (int i = 0; i < WI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
@@ -666,15 +674,15 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
     if (++c_kt == nk) {  // output tile complete
       const int tile_m = c_tile / tiles_n, tile_n = c_tile - tile_m * tiles_n;
       if (out_f32) {
-        nt_epilogue<MODE>(g, acc, tile_m * BM, tile_n * BN, wm, wn, lane, bias, out, relu, out_f32, beta);
+        nt_epilogue<MODE, WI>(g, acc, tile_m * BM, tile_n * TN_, wm, wn, lane, bias, out, relu, out_f32, beta);
       } else {
         // the buffer that was just multiplied is free once every wave has finished reading it
         __syncthreads();
-        nt_epilogue_lds<MODE>(g, acc, tile_m * BM, tile_n * BN, wm, wn, lane, bias, reinterpret_cast<bf16*>(out),
-                              relu, beta, cbuf + wave * (64 * 64));
+        nt_epilogue_lds<MODE, WI>(g, acc, tile_m * BM, tile_n * TN_, wm, wn, lane, bias,
+                                  reinterpret_cast<bf16*>(out), relu, beta, cbuf + wave * (64 * WI * 16));
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < WI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
       c_kt = 0;
@@ -693,8 +701,8 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
     __syncthreads();
     if (c_tile >= ntiles) break;
     if (s_tile < ntiles) stage(0);
-    compute(smem + (BM + BN) * BK);
-    finish_ktile(smem + (BM + BN) * BK);
+    compute(smem + (BM + TN_) * BK);
+    finish_ktile(smem + (BM + TN_) * BK);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
@@ -1208,6 +1216,14 @@ int nt_variant() {
   }();
   return v;
 }
+// widest channel count that still takes the 64-channel tile (VC_NT_NARROW overrides, for tuning runs)
+int nt_narrow() {
+  static const int v = [] {
+    const char* e = getenv("VC_NT_NARROW");
+    return e ? atoi(e) : 64;
+  }();
+  return v;
+}
 int nt_persist_blocks() {
   static const int v = [] {
     const char* e = getenv("VC_NT_BLOCKS");
@@ -1243,9 +1259,16 @@ int launch_nt(const ConvGeom& g, int dtype, const void* src, const void* wgt, co
     VC_CHECK_SHAPE(g.Ci % 8 == 0, "%s: bf16 path needs source channels %% 8 == 0 (got %d)", who, g.Ci);
     const int tiles = ceil_div(g.M, BM) * ceil_div(g.Co, BN);
     if (use_glds() && g.Ci % BK == 0 && g.ldi % 8 == 0 && g.K >= BK && nt_variant() == 2) {
-      const int grid = tiles < nt_persist_blocks() ? tiles : nt_persist_blocks();
-      hipLaunchKernelGGL((igemm_nt_persist_kernel<MODE>), dim3(grid), dim3(NTHR), 0, stream, g, (const bf16*)src,
-                         (const bf16*)wgt, bias, out, relu, out_f32, beta, tiles);
+      if (g.Co <= nt_narrow()) {  // a 128-wide channel tile would be half padding
+        const int t64 = ceil_div(g.M, BM) * ceil_div(g.Co, 64);
+        const int grid = t64 < nt_persist_blocks() * 3 / 2 ? t64 : nt_persist_blocks() * 3 / 2;
+        hipLaunchKernelGGL((igemm_nt_persist_kernel<MODE, 64>), dim3(grid), dim3(NTHR), 0, stream, g,
+                           (const bf16*)src, (const bf16*)wgt, bias, out, relu, out_f32, beta, t64);
+      } else {
+        const int grid = tiles < nt_persist_blocks() ? tiles : nt_persist_blocks();
+        hipLaunchKernelGGL((igemm_nt_persist_kernel<MODE, 128>), dim3(grid), dim3(NTHR), 0, stream, g,
+                           (const bf16*)src, (const bf16*)wgt, bias, out, relu, out_f32, beta, tiles);
+      }
     } else if (use_glds() && g.Ci % BK == 0 && g.ldi % 8 == 0 && nt_variant() >= 1)
       hipLaunchKernelGGL((igemm_nt_fast_kernel<MODE>), dim3(tiles), dim3(NTHR), 0, stream, g, (const bf16*)src,
                          (const bf16*)wgt, bias, out, relu, out_f32, beta);
