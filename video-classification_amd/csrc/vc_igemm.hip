@@ -888,11 +888,27 @@ struct RowInfo {
   int d0, h0, w0;  // window origin coordinates; h0 = -2^28 marks a row beyond the split
 };
 
+// Block swizzle of a pixel-major LDS tile whose rows are W elements (W/16 blocks of 16 columns): the value is
+// XORed into the block index.  It is chosen so that the 32 lanes one transposing read serves (rows 8*gq + q,
+// gq in {0,1}, q in 0..3, four 8-byte pieces each) fall on 64 different banks.
+template <int W>
+__device__ __forceinline__ int tile_swz(int row) {
+  if (W == 128) return (row & 3) | ((row >> 1) & 4);
+  return ((row >> 1) & 1) | (((row >> 3) & 1) << 1);  // W == 64: a row is half a bank sweep
+}
+
+// TCO x TCOL output tile (output channels x gather columns), each 128 or 64: the 64-wide forms serve layers
+// with <= 64 output channels or <= 64 reduction columns, which would leave half of a 128-wide tile empty.
+template <int TCO, int TCOL>
 __global__ __launch_bounds__(NTHR, 2) void igemm_tn_wgrad_fast_kernel(ConvGeom g, const bf16* __restrict__ x,
                                                                       const bf16* __restrict__ dy, int ldy,
                                                                       float* __restrict__ dw, int m_per_split,
                                                                       int ntiles, int tiles_col) {
-  __shared__ __attribute__((aligned(1024))) bf16 smem[2 * 2 * BK * 128];
+  constexpr int STAGE = BK * (TCO + TCOL);  // elements per pipeline stage: dY tile then X tile
+  constexpr int LY = TCO / 8, RY = NTHR / LY, PY = BK / RY;     // dY: lanes per row, rows per pass, passes
+  constexpr int LX = TCOL / 8, RX = NTHR / LX, PX = BK / RX;    // X likewise
+  constexpr int WI = TCO / 32, WJ = TCOL / 32;                  // 16x16 tiles per wave
+  __shared__ __attribute__((aligned(1024))) bf16 smem[2 * STAGE];
   __shared__ __attribute__((aligned(16))) RowInfo rinfo[2][BK];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -902,20 +918,23 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_tn_wgrad_fast_kernel(ConvGeom g
   xcd_remap(logical);
   const int split = logical / ntiles, tile = logical - split * ntiles;
   const int tile_co = tile / tiles_col, tile_col = tile - tile_co * tiles_col;
-  const int co0 = tile_co * 128, col0 = tile_col * 128;
+  const int co0 = tile_co * TCO, col0 = tile_col * TCOL;
   const int m_begin = split * m_per_split;
   const int m_end = min(g.M, m_begin + m_per_split);
   const bf16* zero = reinterpret_cast<const bf16*>(vc_zero_src);
 
-  const int pchunk = tid & 15, lrow = tid >> 4;
-  const int lchunk = ((((pchunk >> 1) ^ tn_swz(lrow)) << 1) | (pchunk & 1));
+  // staging roles (the LDS image is lane-linear per wave instruction; the swizzle is applied to the source)
+  const int ypc = tid % LY, yrow = tid / LY;
+  const int ychunk = ((((ypc >> 1) ^ tile_swz<TCO>(yrow)) << 1) | (ypc & 1));
+  const int xpc = tid % LX, xrow = tid / LX;
+  const int xchunk = ((((xpc >> 1) ^ tile_swz<TCOL>(xrow)) << 1) | (xpc & 1));
   // this thread's gather column (tap, channel chunk) is fixed for the whole kernel
-  const int col = col0 + lchunk * 8;
+  const int col = col0 + xchunk * 8;
   const bool colvalid = col < g.K;
   int rd, rh, rw, c;
   decode_chunk(g, col >> 3, rd, rh, rw, c);
   const int tapoff = ((rd * g.Hi + rh) * g.Wi + rw) * g.ldi + c;
-  const int co_ld = co0 + lchunk * 8;
+  const int co_ld = co0 + ychunk * 8;
   const bool covalid = co_ld < g.Co;
 
   auto decode_rows = [&](int mt, int slot, int t) {  // t in [0, BK): one row per calling thread
@@ -934,52 +953,53 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_tn_wgrad_fast_kernel(ConvGeom g
     rinfo[slot][t] = ri;
   };
 
-  const bf16* yp[4];
+  const bf16* yp[PY];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) yp[i] = dy + (size_t)(m_begin + lrow + 16 * i) * ldy + co_ld;
+  for (int i = 0; i < PY; ++i) yp[i] = dy + (size_t)(m_begin + yrow + RY * i) * ldy + co_ld;
   const int yinc = BK * ldy;
 
   auto stage = [&](int mt, int buf) {
-    bf16* sY = smem + buf * (2 * BK * 128);
-    bf16* sX = sY + BK * 128;
-    int4 ri[4];
+    bf16* sY = smem + buf * STAGE;
+    bf16* sX = sY + BK * TCO;
+    int4 ri[PX];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ri[i] = *reinterpret_cast<const int4*>(&rinfo[buf][lrow + 16 * i]);
+    for (int i = 0; i < PX; ++i) ri[i] = *reinterpret_cast<const int4*>(&rinfo[buf][xrow + RX * i]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      // branch-free: every test is evaluated, the pointers are selected
-      const int mvalid = (mt + lrow + 16 * i < m_end) & (int)covalid;
+    for (int i = 0; i < PY; ++i) {
+      const int mvalid = (mt + yrow + RY * i < m_end) & (int)covalid;
+      const bf16* ysrc = mvalid ? yp[i] : zero;
+      glds16(ysrc, sY + (RY * i + (RY / 4) * wave) * TCO);
+      yp[i] += yinc;
+    }
+#pragma unroll
+    for (int i = 0; i < PX; ++i) {
+      // branch-free: every test is evaluated, the pointer is selected
       const int xok = (int)colvalid & (int)((unsigned)(ri[i].y + rd) < (unsigned)g.Di) &
                       (int)((unsigned)(ri[i].z + rh) < (unsigned)g.Hi) &
                       (int)((unsigned)(ri[i].w + rw) < (unsigned)g.Wi);
       const int xo = xok ? ri[i].x + tapoff : 0;
       const bf16* xsrc = xok ? x + xo : zero;
-      const bf16* ysrc = mvalid ? yp[i] : zero;
-      glds16(ysrc, sY + (16 * i + 4 * wave) * 128);
-      glds16(xsrc, sX + (16 * i + 4 * wave) * 128);
-      yp[i] += yinc;
+      glds16(xsrc, sX + (RX * i + (RX / 4) * wave) * TCOL);
     }
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[WI][WJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < WI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < WJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // transposing fragment reads: lane (gq, q, p) reads rows 8*gq + q (+4) (+32*ks) of a 16-column block;
-  // the row's block swizzle (row & 3) | ((row >> 1) & 4) is the same for all of them
+  // transposing fragment reads: lane (gq, q, p) reads rows 8*gq + q (+4) (+32*ks) of a 16-column block; the
+  // rows' block swizzle is the same for all of them
   const int gq = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
-  const int swz = q | ((gq & 1) << 2);
-  const int rbase = (8 * gq + q) * 128 + p * 4;
-  int yo[4], xo[4];
+  const int r0 = 8 * gq + q;
+  int yo[WI], xo[WJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    yo[i] = rbase + (((wn * 4 + i) ^ swz) << 4);
-    xo[i] = BK * 128 + rbase + (((wm * 4 + i) ^ swz) << 4);
-  }
+  for (int i = 0; i < WI; ++i) yo[i] = r0 * TCO + p * 4 + (((wn * WI + i) ^ tile_swz<TCO>(r0)) << 4);
+#pragma unroll
+  for (int j = 0; j < WJ; ++j) xo[j] = BK * TCO + r0 * TCOL + p * 4 + (((wm * WJ + j) ^ tile_swz<TCOL>(r0)) << 4);
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-  auto frag = [&](const bf16* tile, int off) {
+  auto frag = [&](const bf16* tile, int off, int w) {
     union {
       struct {
         s16x4 a, b;
@@ -987,22 +1007,21 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_tn_wgrad_fast_kernel(ConvGeom g
       bf16x8 v;
     } u;
     u.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + off));
-    u.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + off + 4 * 128));
+    u.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + off + 4 * w));
     return u.v;
   };
   auto compute = [&](const bf16* tile) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 yf[4], xf[4];
+      bf16x8 yf[WI], xf[WJ];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        yf[i] = frag(tile, yo[i] + ks * 32 * 128);
-        xf[i] = frag(tile, xo[i] + ks * 32 * 128);
-      }
+      for (int i = 0; i < WI; ++i) yf[i] = frag(tile, yo[i] + ks * 32 * TCO, TCO);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < WJ; ++j) xf[j] = frag(tile, xo[j] + ks * 32 * TCOL, TCOL);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+      for (int i = 0; i < WI; ++i)
+#pragma unroll
+        for (int j = 0; j < WJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], xf[j], acc[i][j], 0, 0, 0);
     }
   };
@@ -1024,20 +1043,20 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_tn_wgrad_fast_kernel(ConvGeom g
     // tile mt + BK in buffer 1
     if (mt + 2 * BK < m_end) stage(mt + 2 * BK, 0);
     if (tid < BK) decode_rows(mt + 3 * BK, 1, tid);
-    compute(smem + 2 * BK * 128);
+    compute(smem + STAGE);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < WI; ++i) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int co = co0 + wn * 64 + i * 16 + (lane >> 4) * 4 + r;
+      const int co = co0 + wn * (TCO / 2) + i * 16 + (lane >> 4) * 4 + r;
       if (co >= g.Co) continue;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int cc = col0 + wm * 64 + j * 16 + (lane & 15);
+      for (int j = 0; j < WJ; ++j) {
+        const int cc = col0 + wm * (TCOL / 2) + j * 16 + (lane & 15);
         if (cc < g.K) atomicAdd(dw + (size_t)co * g.K + cc, acc[i][j][r]);
       }
     }
@@ -1242,6 +1261,14 @@ bool use_generic_nt() {
   return v != 0;
 }
 
+int wgrad_narrow() {
+  static const int v = [] {
+    const char* e = getenv("VC_WGRAD_NARROW");
+    return e ? atoi(e) : 1;
+  }();
+  return v;
+}
+
 // number of blocks the weight-gradient launch aims for (VC_WGRAD_BLOCKS overrides, for tuning runs)
 int wgrad_target_blocks() {
   static const int v = [] {
@@ -1362,16 +1389,37 @@ int vc_conv_wgrad(const int* desc, int dtype, const void* x, int ldx, const void
   VC_CHECK_SHAPE(dtype != VC_BF16 || (g.ldi % 8 == 0 && ldy_ % 8 == 0), "vc_conv_wgrad: bf16 path needs ld %% 8 == 0");
   if (dtype == VC_BF16 && !force_naive) {
     VC_CHECK_SHAPE(g.Ci % 8 == 0 && g.Co % 8 == 0, "vc_conv_wgrad: bf16 path needs Ci %% 8 == 0 and Co %% 8 == 0");
-    const int tiles_co = ceil_div(g.Co, 128), tiles_col = ceil_div(g.K, 128);
+    const bool fast = use_glds() && !use_generic_nt();
+    int tco = (fast && g.Co <= 64 && wgrad_narrow()) ? 64 : 128;
+    int tcol = (fast && g.K <= 64 && wgrad_narrow()) ? 64 : 128;
+    // measured on the ResNet-50 shapes: short pixel ranges (late stages) and wide 1x1 layers run 5-15% faster
+    // with three narrower blocks per CU than with two 128x128 ones
+    const bool taps1 = g.kd * g.kh * g.kw == 1;
+    if (fast && wgrad_narrow() == 1 && tco == 128 && tcol == 128 &&
+        (g.M <= 131072 || (taps1 && (g.Ci >= 512 || g.Co >= 512))))
+      tcol = 64;
+    if (fast && wgrad_narrow() == 2) tco = 64;   // tuning runs: force the narrow forms
+    if (fast && wgrad_narrow() == 3) tcol = 64;
+    const int tiles_co = ceil_div(g.Co, tco), tiles_col = ceil_div(g.K, tcol);
     const int ntiles = tiles_co * tiles_col;
-    int splits = ceil_div(wgrad_target_blocks(), ntiles);
+    int splits = ceil_div(wgrad_target_blocks() * (tco + tcol < 256 ? 3 : 2) / 2, ntiles);
     const int max_splits = ceil_div(g.M, BK);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     int mps = ceil_div(ceil_div(g.M, splits), BK) * BK;
     splits = ceil_div(g.M, mps);
-    if (use_glds() && !use_generic_nt())
-      hipLaunchKernelGGL(igemm_tn_wgrad_fast_kernel, dim3(ntiles * splits), dim3(NTHR), 0, stream, g, (const bf16*)x,
+    const dim3 grid(ntiles * splits);
+    if (fast && tco == 64 && tcol == 64)
+      hipLaunchKernelGGL((igemm_tn_wgrad_fast_kernel<64, 64>), grid, dim3(NTHR), 0, stream, g, (const bf16*)x,
+                         (const bf16*)dy, ldy_, dw_packed, mps, ntiles, tiles_col);
+    else if (fast && tco == 64)
+      hipLaunchKernelGGL((igemm_tn_wgrad_fast_kernel<64, 128>), grid, dim3(NTHR), 0, stream, g, (const bf16*)x,
+                         (const bf16*)dy, ldy_, dw_packed, mps, ntiles, tiles_col);
+    else if (fast && tcol == 64)
+      hipLaunchKernelGGL((igemm_tn_wgrad_fast_kernel<128, 64>), grid, dim3(NTHR), 0, stream, g, (const bf16*)x,
+                         (const bf16*)dy, ldy_, dw_packed, mps, ntiles, tiles_col);
+    else if (fast)
+      hipLaunchKernelGGL((igemm_tn_wgrad_fast_kernel<128, 128>), grid, dim3(NTHR), 0, stream, g, (const bf16*)x,
                          (const bf16*)dy, ldy_, dw_packed, mps, ntiles, tiles_col);
     else if (use_glds())
       hipLaunchKernelGGL((igemm_tn_wgrad_bf16_kernel<true>), dim3(ntiles * splits), dim3(NTHR), 0, stream, g,
