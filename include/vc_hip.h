@@ -48,6 +48,13 @@ const char* vc_last_error(void);
  * ld* = 0 means dense rows.  beta != 0 adds the result to what `y`/`dx` already hold. */
 int vc_conv_fwd(const int* desc, int dtype, const void* x, int ldx, const void* w_packed, const float* bias, void* y,
                 int ldy, int relu, int out_f32, int beta, vc_stream_t stream);
+/* Forward convolution that also produces the BatchNorm statistics of its output (conv -> BN pairs of the ResNet
+ * trunk, model_components.py:164-176; torchvision Bottleneck): bn_partial[slab][0][c] / [slab][1][c] receive the sum
+ * and sum of squares of y over slab = 64 consecutive output rows, [ceil(M/64)][2][co] fp32, every entry written.
+ * vc_conv_fwd_stats_supported() says whether a geometry can take this path (1) or needs vc_conv_fwd + vc_bn_stats (0). */
+int vc_conv_fwd_stats_supported(const int* desc, int dtype, int ldx, int out_f32);
+int vc_conv_fwd_stats(const int* desc, int dtype, const void* x, int ldx, const void* w_packed, const float* bias,
+                      void* y, int ldy, int relu, float* bn_partial, vc_stream_t stream);
 int vc_conv_dgrad(const int* desc, int dtype, const void* dy, int lddy, const void* w_packed_t, void* dx, int lddx,
                   int out_f32, int beta, vc_stream_t stream);
 /* dw_packed (fp32 [co][taps][ci]) is accumulated into with atomics: the caller zeroes it. */
@@ -74,6 +81,9 @@ int vc_unpack_wgrad(float* dw_packed, float* dw, int co, int ci, int taps, int c
  * per-time-step statistics and its T ordered running-stat updates (encoder loops at :119, :174, :281).
  * sum/sumsq/s1/s2 are [G][C] fp32 accumulated with atomics: the caller zeroes them. */
 int vc_bn_stats(int dtype, const void* y, float* sum, float* sumsq, int G, int rpg, int C, vc_stream_t stream);
+/* the same sums from the slab partials of vc_conv_fwd_stats (rpg = 64 * spg rows per group) */
+int vc_bn_stats_from_partial(const float* partial, float* sum, float* sumsq, int G, int spg, int C,
+                             vc_stream_t stream);
 /* flags: bit 0 = apply the G ordered momentum updates to running_mean/var; bit 1 = zero sum/sumsq after reading */
 int vc_bn_finalize(float* sum, float* sumsq, const float* gamma, const float* beta, float* running_mean,
                    float* running_var, float* mean, float* invstd, float* scale, float* shift, int G, int C, int rpg,

@@ -134,3 +134,40 @@ def test_bad_shape_is_reported(cuda):
     t = torch.zeros(8, device=cuda)
     with pytest.raises(RuntimeError, match="output extent"):
         L.call("vc_conv_fwd", desc, 1, L.ptr(t), 0, L.ptr(t), L.ptr(None), L.ptr(t), 0, 0, 0, 0, L.stream())
+
+
+@pytest.mark.parametrize("shape", [(5, 12, 12, 64, 256, 1), (3, 14, 13, 64, 64, 3), (2, 9, 11, 256, 40, 1)],
+                         ids=["1x1_64_256", "3x3_64_64", "1x1_256_40"])
+def test_conv_fwd_with_bn_slab_sums(cuda, shape):
+    """vc_conv_fwd_stats: same y as vc_conv_fwd (bit-exact) and slab sums equal to sums over the stored y."""
+    from video_classification_amd import _lib as L
+    N, H, W, Ci, Co, k = shape
+    g = torch.Generator().manual_seed(7)
+    p = k // 2
+    cop = (Co + 7) // 8 * 8
+    x = torch.randn(N, 1, H, W, Ci, generator=g).to(cuda, torch.bfloat16)
+    wf = (torch.randn(cop, k * k, Ci, generator=g) * 0.1).to(cuda, torch.bfloat16)
+    wf[Co:] = 0
+    desc = L.int_array([N, 1, H, W, Ci, 1, H, W, cop, 1, k, k, 1, 1, 1, 0, p, p])
+    assert L.query("vc_conv_fwd_stats_supported", desc, 1, 0, 0) == 1
+    M = N * H * W
+    slabs = (M + 63) // 64
+    y0 = torch.empty(M, cop, device=cuda, dtype=torch.bfloat16)
+    y1 = torch.empty_like(y0)
+    part = torch.full((slabs, 2, cop), float("nan"), device=cuda)
+    L.call("vc_conv_fwd", desc, 1, L.ptr(x), 0, L.ptr(wf), L.ptr(None), L.ptr(y0), 0, 0, 0, 0, L.stream())
+    L.call("vc_conv_fwd_stats", desc, 1, L.ptr(x), 0, L.ptr(wf), L.ptr(None), L.ptr(y1), 0, 0, L.ptr(part), L.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    yf = y1.float().cpu()
+    pad = slabs * 64 - M
+    yp = torch.cat([yf, yf.new_zeros(pad, cop)]).view(slabs, 64, cop)
+    ref = torch.stack([yp.sum(1), (yp * yp).sum(1)], 1)
+    assert not torch.isnan(part).any()
+    assert _rel(part.cpu(), ref) < 1e-5
+    # group sums from the partials
+    sums = torch.zeros(2, 1, cop, device=cuda)
+    if M % 64 == 0:
+        L.call("vc_bn_stats_from_partial", L.ptr(part), L.ptr(sums[0]), L.ptr(sums[1]), 1, slabs, cop, L.stream())
+        torch.cuda.synchronize()
+        assert _rel(sums[:, 0].cpu(), ref.sum(0)) < 1e-5

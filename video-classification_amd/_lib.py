@@ -73,6 +73,12 @@ def call(name, *args):
     check(fn(*cargs), name)
 
 
+def query(name, *args):
+    """Call an entry point that returns a value (not a status code); ints are passed as C int."""
+    fn = getattr(lib(), name)
+    return fn(*[ctypes.c_int(int(a)) if isinstance(a, (bool, int)) else a for a in args])
+
+
 def i64(v):
     return ctypes.c_int64(int(v))
 

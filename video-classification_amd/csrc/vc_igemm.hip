@@ -482,7 +482,8 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_fast_kernel(ConvGeom g, cons
 template <int MODE, int WI>
 __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[WI][4], int m0, int n0, int wm,
                                                 int wn, int lane, const float* __restrict__ bias,
-                                                bf16* __restrict__ out, int relu, int beta, bf16* stage_buf) {
+                                                bf16* __restrict__ out, int relu, int beta, bf16* stage_buf,
+                                                float* __restrict__ bn_partial) {
   constexpr int WC = WI * 16;   // channels per wave (64 or 32)
   constexpr int NCH = WC / 8;   // 16-byte chunks per image row (8 or 4)
   const int l15 = lane & 15, q = lane >> 4;
@@ -514,11 +515,22 @@ __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[
   constexpr int RPI = 64 / NCH;  // image rows per store instruction (8 or 16)
   const int rr = lane / NCH, ch = lane % NCH;
   const int co = n0 + wn * WC + ch * 8;
+  float ps[8], pq[8];  // per-channel sum / sum of squares of the values as stored (BatchNorm statistics)
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ps[e] = pq[e] = 0.f;
 #pragma unroll
   for (int it = 0; it < 64 / RPI; ++it) {
     const int row = it * RPI + rr;
     const int m = m0 + wm * 64 + row;
     bf16x8 v = *reinterpret_cast<const bf16x8*>(stage_buf + row * WC + ((ch ^ (row & (NCH - 1))) << 3));
+    if (bn_partial && m < g.M) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float t = (float)v[e];
+        ps[e] += t;
+        pq[e] = fmaf(t, t, pq[e]);
+      }
+    }
     if (m < g.M && co < g.Co) {
       bf16* op = out + (size_t)(MODE == 2 ? phase_out_pixel(g, m) : m) * g.ldc + co;
       if (co + 7 < g.Co && (g.ldc & 7) == 0) {
@@ -546,6 +558,28 @@ __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[
       }
     }
   }
+  if (bn_partial) {
+    // fold the lanes that hold the same channels (they differ in rr) and let rr == 0 write the slab's row:
+    // bn_partial[slab][0][co] = sum, [slab][1][co] = sum of squares over the slab's 64 pixel rows
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int o = NCH; o < 64; o <<= 1) {
+        ps[e] += __shfl_xor(ps[e], o, 64);
+        pq[e] += __shfl_xor(pq[e], o, 64);
+      }
+    }
+    if (rr == 0 && co < g.Co && m0 + wm * 64 < g.M) {
+      const int slab = (m0 + wm * 64) >> 6;
+      float* d = bn_partial + (size_t)slab * 2 * g.Co + co;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (co + e < g.Co) {
+          d[e] = ps[e];
+          d[g.Co + e] = pq[e];
+        }
+    }
+  }
 }
 
 // Persistent form of the fast NT kernel: a block walks output tiles v, v + G, v + 2G, ... and its staging
@@ -557,7 +591,8 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
                                                                    const bf16* __restrict__ wgt,
                                                                    const float* __restrict__ bias,
                                                                    void* __restrict__ out, int relu, int out_f32,
-                                                                   int beta, int ntiles) {
+                                                                   int beta, int ntiles,
+                                                                   float* __restrict__ bn_partial) {
   __shared__ __attribute__((aligned(1024))) bf16 smem[2 * (BM + TN_) * BK];
   constexpr int WI = TN_ / 32;   // 16-channel tiles per wave
   constexpr int NWROW = TN_ / 32;  // weight rows staged per thread
@@ -679,7 +714,8 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
         // the buffer that was just multiplied is free once every wave has finished reading it
         __syncthreads();
         nt_epilogue_lds<MODE, WI>(g, acc, tile_m * BM, tile_n * TN_, wm, wn, lane, bias,
-                                  reinterpret_cast<bf16*>(out), relu, beta, cbuf + wave * (64 * WI * 16));
+                                  reinterpret_cast<bf16*>(out), relu, beta, cbuf + wave * (64 * WI * 16),
+                                  bn_partial);
       }
 #pragma unroll
       for (int i = 0; i < WI; ++i)
@@ -1279,22 +1315,31 @@ int wgrad_target_blocks() {
   return v;
 }
 
+bool nt_persist_eligible(const ConvGeom& g, int dtype) {
+  return dtype == VC_BF16 && use_glds() && g.Ci % BK == 0 && g.ldi % 8 == 0 && g.K >= BK && nt_variant() == 2;
+}
+
 template <int MODE>
 int launch_nt(const ConvGeom& g, int dtype, const void* src, const void* wgt, const float* bias, void* out, int relu,
-              int out_f32, int beta, hipStream_t stream, const char* who) {
+              int out_f32, int beta, hipStream_t stream, const char* who, float* bn_partial = nullptr) {
+  if (bn_partial && !(nt_persist_eligible(g, dtype) && !out_f32 && !beta)) {
+    vc_set_error("%s: fused BatchNorm statistics need the bf16 persistent kernel (source channels %% 64 == 0, "
+                 "bf16 output, beta = 0); ask vc_conv_fwd_stats_supported() first", who);
+    return VC_ERR_SHAPE;
+  }
   if (dtype == VC_BF16) {
     VC_CHECK_SHAPE(g.Ci % 8 == 0, "%s: bf16 path needs source channels %% 8 == 0 (got %d)", who, g.Ci);
     const int tiles = ceil_div(g.M, BM) * ceil_div(g.Co, BN);
-    if (use_glds() && g.Ci % BK == 0 && g.ldi % 8 == 0 && g.K >= BK && nt_variant() == 2) {
+    if (nt_persist_eligible(g, dtype)) {
       if (g.Co <= nt_narrow()) {  // a 128-wide channel tile would be half padding
         const int t64 = ceil_div(g.M, BM) * ceil_div(g.Co, 64);
         const int grid = t64 < nt_persist_blocks() * 3 / 2 ? t64 : nt_persist_blocks() * 3 / 2;
         hipLaunchKernelGGL((igemm_nt_persist_kernel<MODE, 64>), dim3(grid), dim3(NTHR), 0, stream, g,
-                           (const bf16*)src, (const bf16*)wgt, bias, out, relu, out_f32, beta, t64);
+                           (const bf16*)src, (const bf16*)wgt, bias, out, relu, out_f32, beta, t64, bn_partial);
       } else {
         const int grid = tiles < nt_persist_blocks() ? tiles : nt_persist_blocks();
         hipLaunchKernelGGL((igemm_nt_persist_kernel<MODE, 128>), dim3(grid), dim3(NTHR), 0, stream, g,
-                           (const bf16*)src, (const bf16*)wgt, bias, out, relu, out_f32, beta, tiles);
+                           (const bf16*)src, (const bf16*)wgt, bias, out, relu, out_f32, beta, tiles, bn_partial);
       }
     } else if (use_glds() && g.Ci % BK == 0 && g.ldi % 8 == 0 && nt_variant() >= 1)
       hipLaunchKernelGGL((igemm_nt_fast_kernel<MODE>), dim3(tiles), dim3(NTHR), 0, stream, g, (const bf16*)src,
@@ -1332,6 +1377,25 @@ int vc_conv_fwd(const int* desc, int dtype, const void* x, int ldx, const void* 
   VC_CHECK_SHAPE(g.ldc >= g.Co && g.ldi >= g.Ci, "vc_conv_fwd: leading dimension smaller than channel count");
   VC_CHECK_SHAPE(dtype != VC_BF16 || g.ldi % 8 == 0, "vc_conv_fwd: bf16 path needs ldx %% 8 == 0");
   return launch_nt<0>(g, dtype, x, w_packed, bias, y, relu, out_f32, beta, stream, "vc_conv_fwd");
+}
+
+int vc_conv_fwd_stats_supported(const int* desc, int dtype, int ldx, int out_f32) {
+  ConvGeom g;
+  if (fill_geom(g, desc, 0, "vc_conv_fwd_stats_supported")) return 0;
+  if (ldx > 0) g.ldi = ldx;
+  return (nt_persist_eligible(g, dtype) && !out_f32) ? 1 : 0;
+}
+
+int vc_conv_fwd_stats(const int* desc, int dtype, const void* x, int ldx, const void* w_packed, const float* bias,
+                      void* y, int ldy, int relu, float* bn_partial, hipStream_t stream) {
+  ConvGeom g;
+  int rc = fill_geom(g, desc, 0, "vc_conv_fwd_stats");
+  if (rc) return rc;
+  VC_CHECK_ARG(x && w_packed && y && bn_partial, "vc_conv_fwd_stats: null pointer");
+  if (ldy > 0) g.ldc = ldy;
+  if (ldx > 0) g.ldi = ldx;
+  VC_CHECK_SHAPE(g.ldc >= g.Co && g.ldi >= g.Ci, "vc_conv_fwd_stats: leading dimension smaller than channel count");
+  return launch_nt<0>(g, dtype, x, w_packed, bias, y, relu, 0, 0, stream, "vc_conv_fwd_stats", bn_partial);
 }
 
 int vc_conv_dgrad(const int* desc, int dtype, const void* dy, int lddy, const void* w_packed_t, void* dx, int lddx,

@@ -154,6 +154,24 @@ __global__ void bn_reduce_kernel(const T* __restrict__ y, const T* __restrict__ 
 }
 
 // flags: bit 0 = update the running statistics, bit 1 = zero sum/sumsq after reading them
+// sums[g][c] += sum over the slabs of group g of partial[slab][0][c] (and [1] into sumsq); a block covers
+// `chunk` slabs of one group and 256 channels
+__global__ void bn_partial_reduce_kernel(const float* __restrict__ partial, float* __restrict__ sum,
+                                         float* __restrict__ sumsq, int spg, int C, int chunk) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int g = blockIdx.z;
+  if (c >= C) return;
+  const int s0 = blockIdx.y * chunk, s1 = min(spg, s0 + chunk);
+  float a = 0.f, b = 0.f;
+  for (int sl = s0; sl < s1; ++sl) {
+    const float* p = partial + ((size_t)g * spg + sl) * 2 * C;
+    a += p[c];
+    b += p[C + c];
+  }
+  atomicAdd(sum + g * C + c, a);
+  atomicAdd(sumsq + g * C + c, b);
+}
+
 __global__ void bn_finalize_kernel(float* __restrict__ sum, float* __restrict__ sumsq,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
@@ -529,6 +547,20 @@ int vc_bn_stats(int dtype, const void* y, float* sum, float* sumsq, int G, int r
     launch_reduce<float, 0>(y, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, sum, sumsq, G, rpg, C, 0, stream);
   else { vc_set_error("vc_bn_stats: unsupported dtype %d", dtype); return VC_ERR_DTYPE; }
   VC_LAUNCH_CHECK("vc_bn_stats");
+  return VC_OK;
+}
+
+// partial: [G * spg slabs][2][C] written by vc_conv_fwd_stats (a slab is 64 consecutive rows, rpg = 64 * spg);
+// sum/sumsq [G][C] are accumulated into (the caller keeps them zeroed, as for vc_bn_stats)
+int vc_bn_stats_from_partial(const float* partial, float* sum, float* sumsq, int G, int spg, int C,
+                             hipStream_t stream) {
+  VC_CHECK_ARG(partial && sum && sumsq, "vc_bn_stats_from_partial: null pointer");
+  VC_CHECK_SHAPE(G > 0 && G < 65536 && spg > 0 && C > 0, "vc_bn_stats_from_partial: bad shape");
+  int chunk = 16;
+  while (ceil_div(spg, chunk) * G * ceil_div(C, 256) > 2048) chunk *= 2;
+  const dim3 grid(ceil_div(C, 256), ceil_div(spg, chunk), G);
+  hipLaunchKernelGGL(bn_partial_reduce_kernel, grid, dim3(256), 0, stream, partial, sum, sumsq, spg, C, chunk);
+  VC_LAUNCH_CHECK("vc_bn_stats_from_partial");
   return VC_OK;
 }
 

@@ -81,8 +81,7 @@ class EncoderCNN(_HipModule):
         a = ops.clip_to_frames(x_3d, self.compute_dtype)                      # [T*B,1,H,W,8]
         for i, k in enumerate(self.kernels):
             blk = getattr(self, f"conv{i + 1}")
-            y = ops.conv(a, blk[0].weight, blk[0].bias, (1, k, k), (1, 2, 2), 0)
-            a = ops.batch_norm(y, blk[1], groups=T, relu=True)
+            a = ops.conv_bn(a, blk[0].weight, blk[1], T, blk[0].bias, (1, k, k), (1, 2, 2), 0, relu=True)
         # flatten(NCHW) + fc1 == a convolution whose kernel covers the whole feature map
         hf, wf = self.feat_hw
         y = ops.conv(a, self.fc1.weight, self.fc1.bias, (1, hf, wf), 1, 0, relu=True, ci=a.shape[-1])
@@ -119,14 +118,12 @@ class Bottleneck(nn.Module):
         if self.downsample is not None:
             # evaluated before conv1 so that its backward runs after conv1's: the strided 1x1 data gradient then
             # only ADDS into the pixels it reaches instead of also zero-filling the rest of the buffer
-            idt = ops.batch_norm(ops.conv(x, self.downsample[0].weight, None, 1, (1, s, s), 0, join=join),
-                                 self.downsample[1], T)
-        a = ops.batch_norm(ops.conv(x, self.conv1.weight, join=join), self.bn1, T, relu=True)
-        a = ops.batch_norm(ops.conv(a, self.conv2.weight, None, (1, 3, 3), (1, s, s), (0, 1, 1)), self.bn2, T, relu=True)
-        y = ops.conv(a, self.conv3.weight)
+            idt = ops.conv_bn(x, self.downsample[0].weight, self.downsample[1], T, None, 1, (1, s, s), 0, join=join)
+        a = ops.conv_bn(x, self.conv1.weight, self.bn1, T, relu=True, join=join)
+        a = ops.conv_bn(a, self.conv2.weight, self.bn2, T, None, (1, 3, 3), (1, s, s), (0, 1, 1), relu=True)
         if idt is not None:
-            return ops.batch_norm(y, self.bn3, T, relu=True, residual=idt)
-        return ops.batch_norm(y, self.bn3, T, relu=True, residual=x, res_join=join)
+            return ops.conv_bn(a, self.conv3.weight, self.bn3, T, relu=True, residual=idt)
+        return ops.conv_bn(a, self.conv3.weight, self.bn3, T, relu=True, residual=x, res_join=join)
 
 
 RESNET_LAYERS = {"resnet50": (3, 4, 6, 3), "resnet101": (3, 4, 23, 3), "resnet152": (3, 8, 36, 3)}

@@ -6,6 +6,8 @@ of 8.  PyTorch only owns the memory and the autograd graph; every arithmetic ste
 into libvc_hip.  Parameter gradients are accumulated by the kernels directly into ``param.grad``
 (fp32), so the autograd functions return ``None`` for parameter inputs.
 """
+import os
+
 import torch
 
 from . import _lib as L
@@ -175,7 +177,7 @@ class _Conv(torch.autograd.Function):
     """y = conv(x, weight) + bias (optionally ReLU) on channels-last tensors."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, kernel, stride, padding, relu, out_f32, ci, join):
+    def forward(ctx, x, weight, bias, kernel, stride, padding, relu, out_f32, ci, join, stats_groups):
         _require_cuda(x, "conv")
         ctx.join = join
         x = x.contiguous()
@@ -214,18 +216,31 @@ class _Conv(torch.autograd.Function):
         f32 = bool(out_f32) or dtype == torch.float32
         y = torch.empty(N, Do, Ho, Wo, cop, device=x.device, dtype=torch.float32 if f32 else dtype)
         flops = 2.0 * N * Do * Ho * Wo * co * ci * taps  # algorithmic: true channel counts, no padding
-        _timed("conv_fwd", flops, lambda: L.call(
-            "vc_conv_fwd", L.int_array(desc), L.dtype_code(dtype), L.ptr(x), 0, L.ptr(wf), L.ptr(b), L.ptr(y), 0,
-            int(relu), int(f32), 0, L.stream()))
+        M = N * Do * Ho * Wo
+        partial = None
+        if (stats_groups and FUSE_BN_STATS and not f32 and M % stats_groups == 0 and (M // stats_groups) % 64 == 0 and
+                L.query("vc_conv_fwd_stats_supported", L.int_array(desc), L.dtype_code(dtype), 0, 0) == 1):
+            # the BatchNorm that follows takes its statistics from 64-row slab sums written by the epilogue
+            partial = torch.empty(M // 64, 2, cop, device=x.device, dtype=torch.float32)
+            _timed("conv_fwd", flops, lambda: L.call(
+                "vc_conv_fwd_stats", L.int_array(desc), L.dtype_code(dtype), L.ptr(x), 0, L.ptr(wf), L.ptr(b),
+                L.ptr(y), 0, int(relu), L.ptr(partial), L.stream()))
+        else:
+            _timed("conv_fwd", flops, lambda: L.call(
+                "vc_conv_fwd", L.int_array(desc), L.dtype_code(dtype), L.ptr(x), 0, L.ptr(wf), L.ptr(b), L.ptr(y), 0,
+                int(relu), int(f32), 0, L.stream()))
         ctx.flops = flops
         ctx.desc, ctx.taps, ctx.relu, ctx.has_bias = desc, taps, relu, bias is not None
         ctx.dims = (co, ci, cip, cop)
         ctx.weight, ctx.bias = weight, bias
         ctx.save_for_backward(x, wt, y if relu else None)
-        return y
+        if partial is None:
+            partial = y.new_empty(0, dtype=torch.float32)
+        ctx.mark_non_differentiable(partial)
+        return y, partial
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dpartial=None):
         x, wt, y = ctx.saved_tensors
         co, ci, cip, cop = ctx.dims
         dtype = x.dtype
@@ -262,7 +277,11 @@ class _Conv(torch.autograd.Function):
                 int(acc), L.stream()))
             if join is not None:
                 dx = join.arrive(dx)
-        return dx, None, None, None, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None, None, None, None
+
+
+# VC_FUSE_BN_STATS=0 keeps BatchNorm statistics in their own pass over y (A/B measurements)
+FUSE_BN_STATS = os.environ.get("VC_FUSE_BN_STATS", "1") != "0"
 
 
 class GradJoin:
@@ -288,7 +307,18 @@ def conv(x, weight, bias=None, kernel=1, stride=1, padding=0, relu=False, out_f3
     """x: [N,D,H,W,C] channels-last.  weight: fp32 parameter whose memory is [Co][Ci][taps] (a Conv2d/Conv3d
     weight, or a Linear weight [Co, Ci*taps] read as a convolution over the whole feature map when `ci` is given).
     join: optional GradJoin shared with the other consumers of x."""
-    return _Conv.apply(x, weight, bias, kernel, stride, padding, relu, out_f32, ci, join)
+    return _Conv.apply(x, weight, bias, kernel, stride, padding, relu, out_f32, ci, join, 0)[0]
+
+
+def conv_bn(x, weight, bn, groups, bias=None, kernel=1, stride=1, padding=0, relu=False, residual=None, join=None,
+            res_join=None):
+    """BatchNorm(conv(x)) (+ residual, ReLU).  In training the convolution's epilogue also writes the slab sums
+    the BatchNorm statistics are taken from, where the geometry allows it (otherwise a separate pass reads y)."""
+    training = bn.training or bn.running_mean is None
+    y, partial = _Conv.apply(x, weight, bias, kernel, stride, padding, False, False, None, join,
+                             groups if training else 0)
+    return batch_norm(y, bn, groups, relu=relu, residual=residual, res_join=res_join,
+                      partial=partial if partial.numel() else None)
 
 
 def linear(x, weight, bias=None, relu=False, out_f32=False):
@@ -304,7 +334,7 @@ def linear(x, weight, bias=None, relu=False, out_f32=False):
 class _BatchNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, gamma, beta, running_mean, running_var, groups, momentum, eps, relu, residual, training,
-                res_join, owner):
+                res_join, owner, partial):
         _require_cuda(y, "batch_norm")
         ctx.res_join = res_join
         ctx.owner = owner
@@ -322,7 +352,11 @@ class _BatchNorm(torch.autograd.Function):
             rpg = M // G
             sums = _zero_scratch(owner, "_vc_sums", (2, G, C), dev)  # cleared again by vc_bn_finalize
             stat = torch.empty(4, G, C, device=dev, dtype=torch.float32)  # mean, invstd, scale, shift
-            L.call("vc_bn_stats", code, L.ptr(y), L.ptr(sums[0]), L.ptr(sums[1]), G, rpg, C, L.stream())
+            if partial is not None:
+                L.call("vc_bn_stats_from_partial", L.ptr(partial), L.ptr(sums[0]), L.ptr(sums[1]), G, rpg // 64, C,
+                       L.stream())
+            else:
+                L.call("vc_bn_stats", code, L.ptr(y), L.ptr(sums[0]), L.ptr(sums[1]), G, rpg, C, L.stream())
             upd = running_mean is not None
             L.call("vc_bn_finalize", L.ptr(sums[0]), L.ptr(sums[1]), L.ptr(ga), L.ptr(be), L.ptr(running_mean),
                    L.ptr(running_var), L.ptr(stat[0]), L.ptr(stat[1]), L.ptr(stat[2]), L.ptr(stat[3]), G, C, rpg,
@@ -368,16 +402,16 @@ class _BatchNorm(torch.autograd.Function):
         db = _grad_buf(ctx.beta) if ctx.beta is not None and ctx.beta.requires_grad else None
         L.call("vc_bn_bwd_params", L.ptr(s[0]), L.ptr(s[1]), L.ptr(dg), L.ptr(db), G, C, 3, L.stream())
         _ready(ctx.gamma, ctx.beta)
-        return dy, None, None, None, None, None, None, None, None, dres, None, None, None
+        return dy, None, None, None, None, None, None, None, None, dres, None, None, None, None
 
 
-def batch_norm(y, bn, groups, relu=False, residual=None, res_join=None):
+def batch_norm(y, bn, groups, relu=False, residual=None, res_join=None, partial=None):
     """bn: an nn.BatchNorm{1,2,3}d module holding the parameters/buffers (its own forward is not used).
     res_join: optional GradJoin shared with the other consumers of `residual`."""
     training = bn.training or bn.running_mean is None
     out = _BatchNorm.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, groups,
                            bn.momentum if bn.momentum is not None else 0.1, bn.eps, relu, residual, training,
-                           res_join, bn)
+                           res_join, bn, partial)
     if training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked += groups
     return out
