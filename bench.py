@@ -211,17 +211,32 @@ def main():
 
     # per-kernel-family time from the HIP events recorded around each contraction launch
     fam = {}
-    for tag, flops, s, e in prof:
-        f = fam.setdefault(tag, [0.0, 0.0, 0])
+    for tag, flops, s, e, nbytes in prof:
+        f = fam.setdefault(tag, [0.0, 0.0, 0, 0.0])
         f[0] += flops
         f[1] += s.elapsed_time(e) * 1e-3
         f[2] += 1
+        f[3] += nbytes
     roof = None
     if "conv_fwd" in fam and fam["conv_fwd"][1] > 0:
-        fl, tm, n = fam["conv_fwd"]
+        fl, tm, n, nb = fam["conv_fwd"]
         ach = fl / tm / 1e12
-        roof = {"bound": "mfma", "kernel": "igemm_nt_bf16_kernel<0> (forward conv/linear)", "achieved": ach,
-                "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+        # HBM bytes per launch of the same kernel family from the PMC passes (tools/pmc_bench.sh, separate runs of
+        # this command with --no-graph; FETCH_SIZE doubled as gfx950 requires) -- None if they were never collected
+        traffic, traffic_src, traffic_step = None, None, None
+        tfile = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        if args.model == "resnetcrnn" and args.arch == "resnet50" and B == 32 and os.path.exists(tfile):
+            with open(tfile) as fh:
+                tj = json.load(fh)
+            if "conv_fwd" in tj.get("families", {}):
+                traffic = tj["families"]["conv_fwd"]["traffic_bytes"]
+                traffic_step = tj["families"]["conv_fwd"].get("traffic_bytes_per_step")
+                traffic_src = "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+        roof = {"bound": "mfma", "kernel": "igemm_nt_persist_kernel<0,*> (forward implicit-GEMM conv/linear)",
+                "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes per launch",
+                "traffic_source": traffic_src, "traffic_bytes_per_step": traffic_step,
+                "algorithmic_bytes_per_launch": nb / n, "algorithmic_bytes_per_step": nb / prof_steps,
                 "launches": n, "avg_launch_ms": tm / n * 1e3, "avg_launch_gflop": fl / n / 1e9,
                 "other_kernels": {k: {"achieved_tflops": v[0] / v[1] / 1e12, "launches": v[2],
                                       "ms_per_step": v[1] / prof_steps * 1e3}

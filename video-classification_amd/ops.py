@@ -26,7 +26,8 @@ def bump_weights_epoch():
 PROFILE = None
 
 
-def _timed(tag, flops, launch):
+def _timed(tag, flops, launch, nbytes=0.0):
+    """Run `launch`; when PROFILE is a list also record (tag, algorithmic flops, HIP events, algorithmic bytes)."""
     if PROFILE is None:
         launch()
         return
@@ -34,7 +35,7 @@ def _timed(tag, flops, launch):
     s.record()
     launch()
     e.record()
-    PROFILE.append((tag, flops, s, e))
+    PROFILE.append((tag, flops, s, e, nbytes))
 
 
 def _require_cuda(t, what):
@@ -218,17 +219,19 @@ class _Conv(torch.autograd.Function):
         flops = 2.0 * N * Do * Ho * Wo * co * ci * taps  # algorithmic: true channel counts, no padding
         M = N * Do * Ho * Wo
         partial = None
+        # algorithmic HBM bytes of one launch: the input, the packed weight and the output, each moved once
+        nbytes = float(x.numel() * x.element_size() + wf.numel() * wf.element_size() + y.numel() * y.element_size())
         if (stats_groups and FUSE_BN_STATS and not f32 and M % stats_groups == 0 and (M // stats_groups) % 64 == 0 and
                 L.query("vc_conv_fwd_stats_supported", L.int_array(desc), L.dtype_code(dtype), 0, 0) == 1):
             # the BatchNorm that follows takes its statistics from 64-row slab sums written by the epilogue
             partial = torch.empty(M // 64, 2, cop, device=x.device, dtype=torch.float32)
             _timed("conv_fwd", flops, lambda: L.call(
                 "vc_conv_fwd_stats", L.int_array(desc), L.dtype_code(dtype), L.ptr(x), 0, L.ptr(wf), L.ptr(b),
-                L.ptr(y), 0, int(relu), L.ptr(partial), L.stream()))
+                L.ptr(y), 0, int(relu), L.ptr(partial), L.stream()), nbytes)
         else:
             _timed("conv_fwd", flops, lambda: L.call(
                 "vc_conv_fwd", L.int_array(desc), L.dtype_code(dtype), L.ptr(x), 0, L.ptr(wf), L.ptr(b), L.ptr(y), 0,
-                int(relu), int(f32), 0, L.stream()))
+                int(relu), int(f32), 0, L.stream()), nbytes)
         ctx.flops = flops
         ctx.desc, ctx.taps, ctx.relu, ctx.has_bias = desc, taps, relu, bias is not None
         ctx.dims = (co, ci, cip, cop)
