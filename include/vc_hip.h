@@ -148,6 +148,18 @@ int vc_window_attn_bwd(int dtype, const void* qkv, const void* dout, const float
                        vc_stream_t stream);
 int vc_patch_merge(int dtype, const void* in, void* out, int B, int H, int W, int C, int inverse, vc_stream_t stream);
 
+/* Persistent recurrence of one nn.LSTM layer (DecoderRNN.LSTM, model_components.py:209-214, 221; TCG_LSTM's
+ * lstm_short / lstm_long, :482-483): all T steps, ndir = 1 or 2 directions (direction 1 walks the sequence in
+ * reverse), in ONE launch with W_hh sharded over workgroups and resident in registers.  Arrays have one entry per
+ * direction: gates_x [T][B][4H] fp32 = x W_ih^T + b_ih + b_hh, w_hh [4H][H] bf16 (gate order i,f,g,o), hs receives
+ * h_t at hs[(t*B + b)*ldh + j], act [T][B][4H] / c [T][B][H] fp32 are what vc_lstm_cell_bwd reads, xchg is scratch
+ * of vc_lstm_persist_xchg_bytes(B, H) bytes (zeroed by the call).  *err (nullable) becomes 1 if a workgroup gave
+ * up waiting for its peers.  vc_lstm_persist_supported() = 1 when (dtype, B, H, ndir) can take this path. */
+long long vc_lstm_persist_xchg_bytes(int B, int H);
+int vc_lstm_persist_supported(int dtype, int B, int H, int ndir);
+int vc_lstm_persist_fwd(int dtype, const float* const* gates_x, const void* const* w_hh, void* const* hs, int ldh,
+                        float* const* act, float* const* c, void* const* xchg, int* err, int T, int B, int H,
+                        int ndir, vc_stream_t stream);
 /* ---- LSTM cell (gate order i,f,g,o; nn.LSTM at model_components.py:209-214, 482-483) -------------- */
 int vc_lstm_cell_fwd(int dtype, const float* gates_x, int ldx, const float* gates_h, const float* c_prev, void* h_out,
                      int ldh, float* c_out, float* act_out, int B, int H, vc_stream_t stream);

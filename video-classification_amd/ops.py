@@ -521,6 +521,27 @@ def _off(t, elems):
     return ctypes.c_void_p(t.data_ptr() + elems * t.element_size())
 
 
+# VC_PERSISTENT_LSTM=0 runs the recurrence as one small GEMM + one cell kernel per time step (A/B, and the
+# path shapes the persistent kernel does not cover fall back to)
+PERSISTENT_LSTM = os.environ.get("VC_PERSISTENT_LSTM", "1") != "0"
+_lstm_err = {}
+
+
+def lstm_error_flag(device):
+    """int32 device word the persistent LSTM kernel sets if a workgroup gave up waiting for its peers."""
+    key = (device.type, device.index)
+    if key not in _lstm_err:
+        _lstm_err[key] = torch.zeros(1, device=device, dtype=torch.int32)
+    return _lstm_err[key]
+
+
+def check_lstm_error():
+    """Synchronising check of the persistent LSTM's error word (tests, end of an epoch)."""
+    for flag in _lstm_err.values():
+        if int(flag.item()) != 0:
+            raise RuntimeError("persistent LSTM kernel: a workgroup timed out waiting for its peers; results invalid")
+
+
 class _LSTM(torch.autograd.Function):
     """x [T,B,In] -> out [T,B,H*dirs]; zero initial state (DecoderRNN passes None; TCG_LSTM uses the default).
 
@@ -542,9 +563,11 @@ class _LSTM(torch.autograd.Function):
         masks = {}
         inp = x
         st = L.stream()
+        persist = PERSISTENT_LSTM and L.query("vc_lstm_persist_supported", code, B, H, dirs) == 1
         for l in range(layers):
             Kin = inp.shape[-1]
             out = torch.empty(T, B, H * dirs, device=dev, dtype=dt)
+            pending = []
             for d in range(dirs):
                 w_ih, w_hh, b_ih, b_hh = params[(l * dirs + d) * 4:(l * dirs + d) * 4 + 4]
                 wih_f, wih_t = _packed_weights(w_ih, Kin, 1, Kin, 4 * H, dt)
@@ -555,6 +578,10 @@ class _LSTM(torch.autograd.Function):
                        L.ptr(gx), 0, 0, 1, 0, st)
                 c = torch.empty(T, B, H, device=dev, dtype=f32)
                 act = torch.empty(T, B, 4 * H, device=dev, dtype=f32)
+                if persist:  # the recurrence of every direction runs below as ONE persistent launch
+                    pending.append((gx, whh_f, c, act))
+                    saved.append((inp, c, act, wih_t, whh_t))
+                    continue
                 gh = torch.empty(B, 4 * H, device=dev, dtype=f32)
                 order = range(T) if d == 0 else range(T - 1, -1, -1)
                 prev = None
@@ -568,6 +595,16 @@ class _LSTM(torch.autograd.Function):
                            _off(act, t * B * 4 * H), B, H, st)
                     prev = t
                 saved.append((inp, c, act, wih_t, whh_t))
+            if pending:
+                import ctypes
+                nb = L.query("vc_lstm_persist_xchg_bytes", B, H)
+                xch = [torch.empty(nb, device=dev, dtype=torch.uint8) for _ in pending]
+                arr = lambda ptrs: (ctypes.c_void_p * len(ptrs))(*ptrs)  # noqa: E731
+                L.call("vc_lstm_persist_fwd", code, arr([p_[0].data_ptr() for p_ in pending]),
+                       arr([p_[1].data_ptr() for p_ in pending]),
+                       arr([out.data_ptr() + d * H * out.element_size() for d in range(dirs)]), H * dirs,
+                       arr([p_[3].data_ptr() for p_ in pending]), arr([p_[2].data_ptr() for p_ in pending]),
+                       arr([x_.data_ptr() for x_ in xch]), L.ptr(lstm_error_flag(dev)), T, B, H, dirs, st)
             saved.append(out)
             inp = out
             if drop_p > 0.0 and l < layers - 1:  # nn.LSTM's inter-layer dropout (training mode only)
