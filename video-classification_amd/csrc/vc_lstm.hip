@@ -21,7 +21,7 @@ namespace {
 constexpr int LTHR = 256;
 constexpr int UNITS = 16;    // hidden units per workgroup
 constexpr int BCHUNK = 32;   // batch rows per workgroup
-constexpr unsigned SPIN_LIMIT = 1u << 22;
+constexpr unsigned SPIN_LIMIT = 1u << 20;
 
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 
@@ -82,20 +82,30 @@ __global__ __launch_bounds__(LTHR, 1) void lstm_persist_fwd_kernel(LstmArgs a) {
     if (ts > 0) {
       // gather h_{t-1}: every granule carries the step that wrote it; spin (bounded) until it is this step's
       gu64* xp = xbase + ((ts - 1) & 1) * per_parity;
-      for (int idx = tid; idx < per_parity; idx += LTHR) {
-        unsigned long long g = __hip_atomic_load(xp + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
-        while ((unsigned)(g >> 32) != (unsigned)ts) {
-          if (++spins > SPIN_LIMIT) {  // a workgroup is missing: give up loudly instead of hanging the GPU
-            if (a.err) atomicExch(a.err, 1);
-            break;
-          }
-          __builtin_amdgcn_s_sleep(1);
-          g = __hip_atomic_load(xp + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      constexpr int NG = NKS * 2;  // granules per thread: (H/2 * 32) / 256
+      unsigned long long g[NG];
+      unsigned spins = 0;
+      for (;;) {
+        // all loads of a sweep are issued back to back (one memory latency per sweep, not per granule)
+#pragma unroll
+        for (int k = 0; k < NG; ++k)
+          g[k] = __hip_atomic_load(xp + tid + LTHR * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < NG; ++k) ok &= (unsigned)(g[k] >> 32) == (unsigned)ts;
+        if (ok) break;
+        if (++spins > SPIN_LIMIT) {  // a workgroup is missing: give up loudly instead of hanging the GPU
+          if (a.err) atomicExch(a.err, 1);
+          break;
         }
+        __builtin_amdgcn_s_sleep(1);
+      }
+#pragma unroll
+      for (int k = 0; k < NG; ++k) {
+        const int idx = tid + LTHR * k;
         const int up = idx >> 5, b = idx & 31;  // unit pair, batch row
         const int chunk = (up >> 2) ^ (b & SWZ);
-        *reinterpret_cast<unsigned*>(sH + b * H + chunk * 8 + 2 * (up & 3)) = (unsigned)g;
+        *reinterpret_cast<unsigned*>(sH + b * H + chunk * 8 + 2 * (up & 3)) = (unsigned)g[k];
       }
     }
     __syncthreads();
