@@ -57,9 +57,10 @@ int vc_conv_fwd_stats(const int* desc, int dtype, const void* x, int ldx, const 
                       void* y, int ldy, int relu, float* bn_partial, vc_stream_t stream);
 int vc_conv_dgrad(const int* desc, int dtype, const void* dy, int lddy, const void* w_packed_t, void* dx, int lddx,
                   int out_f32, int beta, vc_stream_t stream);
-/* dw_packed (fp32 [co][taps][ci]) is accumulated into with atomics: the caller zeroes it. */
+/* dw_packed (fp32 [co][taps][ci]) is accumulated into with atomics: the caller zeroes it.  dbias (nullable, fp32
+ * [co]) receives += the column sums of dy, i.e. the bias gradient of the same layer, from the same pass over dy. */
 int vc_conv_wgrad(const int* desc, int dtype, const void* x, int ldx, const void* dy, int lddy, float* dw_packed,
-                  int force_naive, vc_stream_t stream);
+                  float* dbias, int force_naive, vc_stream_t stream);
 /* cross-check used by the tests: the plain-FMA kernel on bf16 data (mode 0 forward, 1 data gradient) */
 int vc_conv_fwd_naive_bf16(const int* desc, int mode, const void* src, const void* w_packed, const float* bias,
                            void* out, int relu, int out_f32, vc_stream_t stream);

@@ -111,18 +111,20 @@ def test_conv_fwd_dgrad_wgrad(cuda, case, dt):
 
     # weight gradient (MFMA path for bf16, naive path for fp32)
     dwp = torch.zeros(Co, taps, Ci, device=cuda, dtype=torch.float32)
-    L.call("vc_conv_wgrad", d, code, L.ptr(xd), 0, L.ptr(dyd), 0, L.ptr(dwp), 0, L.stream())
+    db = torch.zeros(Co, device=cuda, dtype=torch.float32)  # bias gradient from the same pass over dy
+    L.call("vc_conv_wgrad", d, code, L.ptr(xd), 0, L.ptr(dyd), 0, L.ptr(dwp), L.ptr(db), 0, L.stream())
     dw = torch.empty(Co, Ci, taps, device=cuda, dtype=torch.float32)
     L.call("vc_unpack_wgrad", L.ptr(dwp), L.ptr(dw), Co, Ci, taps, Ci, 0, L.stream())
     torch.cuda.synchronize()
     assert _rel(dw.cpu(), wr.grad.reshape(Co, Ci, taps)) < tol
+    assert _rel(db.cpu(), dy.sum(dim=(0, 2, 3, 4))) < tol
 
     if dt == torch.bfloat16:
         # on-device cross-check: naive kernels on the same bf16 data
         yn = torch.empty_like(y)
         L.call("vc_conv_fwd_naive_bf16", d, 0, L.ptr(xd), L.ptr(wf), L.ptr(bd), L.ptr(yn), 0, 1, L.stream())
         dwn = torch.zeros_like(dwp)
-        L.call("vc_conv_wgrad", d, code, L.ptr(xd), 0, L.ptr(dyd), 0, L.ptr(dwn), 1, L.stream())
+        L.call("vc_conv_wgrad", d, code, L.ptr(xd), 0, L.ptr(dyd), 0, L.ptr(dwn), L.ptr(None), 1, L.stream())
         torch.cuda.synchronize()
         assert _rel(y, yn) < tol
         assert _rel(dwp, dwn) < tol

@@ -89,7 +89,7 @@ def main():
         if Ci % 8 == 0 and "dgrad" in passes:
             t_d = run(lambda: L.call("vc_conv_dgrad", desc, 1, L.ptr(dy), 0, L.ptr(wt), L.ptr(dx), 0, 0, 0, st))
         if "wgrad" in passes:
-            t_w = run(lambda: L.call("vc_conv_wgrad", desc, 1, L.ptr(x), 0, L.ptr(dy), 0, L.ptr(dwp), 0, st))
+            t_w = run(lambda: L.call("vc_conv_wgrad", desc, 1, L.ptr(x), 0, L.ptr(dy), 0, L.ptr(dwp), L.ptr(None), 0, st))
         tf = lambda t: flops / (t * 1e-3) / 1e12  # noqa: E731
         print(f"{name:12s} {f'{N},{H},{W},{Ci}->{Co} k{k} s{s}':34s} {cnt:3d} {flops / 1e9:8.1f} | {tf(t_f):7.0f} {t_f:6.3f} | "
               f"{tf(t_d):8.0f} {t_d:6.3f} | {tf(t_w):8.0f} {t_w:6.3f}")

@@ -939,7 +939,8 @@ template <int TCO, int TCOL>
 __global__ __launch_bounds__(NTHR, 2) void igemm_tn_wgrad_fast_kernel(ConvGeom g, const bf16* __restrict__ x,
                                                                       const bf16* __restrict__ dy, int ldy,
                                                                       float* __restrict__ dw, int m_per_split,
-                                                                      int ntiles, int tiles_col) {
+                                                                      int ntiles, int tiles_col,
+                                                                      float* __restrict__ dbias) {
   constexpr int STAGE = BK * (TCO + TCOL);  // elements per pipeline stage: dY tile then X tile
   constexpr int LY = TCO / 8, RY = NTHR / LY, PY = BK / RY;     // dY: lanes per row, rows per pass, passes
   constexpr int LX = TCOL / 8, RX = NTHR / LX, PX = BK / RX;    // X likewise
@@ -1046,6 +1047,14 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_tn_wgrad_fast_kernel(ConvGeom g
     u.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + off + 4 * w));
     return u.v;
   };
+  // Bias gradient = column sums of dy = dy^T x (a column of ones): the waves that own column tile 0 multiply
+  // their dy fragments by an all-ones operand as well (one extra MFMA per fragment, no extra loads).
+  const bool do_bias = dbias != nullptr && tile_col == 0 && wm == 0;
+  f32x4 bacc[WI];
+#pragma unroll
+  for (int i = 0; i < WI; ++i) bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bf16 one = (bf16)1.0f;
+  const bf16x8 ones = {one, one, one, one, one, one, one, one};
   auto compute = [&](const bf16* tile) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -1054,6 +1063,10 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_tn_wgrad_fast_kernel(ConvGeom g
       for (int i = 0; i < WI; ++i) yf[i] = frag(tile, yo[i] + ks * 32 * TCO, TCO);
 #pragma unroll
       for (int j = 0; j < WJ; ++j) xf[j] = frag(tile, xo[j] + ks * 32 * TCOL, TCOL);
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < WI; ++i) bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], ones, bacc[i], 0, 0, 0);
+      }
 #pragma unroll
       for (int i = 0; i < WI; ++i)
 #pragma unroll
@@ -1096,6 +1109,15 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_tn_wgrad_fast_kernel(ConvGeom g
         if (cc < g.K) atomicAdd(dw + (size_t)co * g.K + cc, acc[i][j][r]);
       }
     }
+  }
+  if (do_bias && (lane & 15) == 0) {  // every column of bacc holds the same sums: lane column 0 adds them
+#pragma unroll
+    for (int i = 0; i < WI; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + wn * (TCO / 2) + i * 16 + (lane >> 4) * 4 + r;
+        if (co < g.Co) atomicAdd(dbias + co, bacc[i][r]);
+      }
   }
 }
 
@@ -1441,8 +1463,10 @@ int vc_conv_dgrad(const int* desc, int dtype, const void* dy, int lddy, const vo
   return launch_nt<1>(g, dtype, dy, w_packed_t, nullptr, dx, 0, out_f32, beta, stream, "vc_conv_dgrad");
 }
 
+extern "C" int vc_colsum(int dtype, const void* a, float* out, int M, int C, int lda, hipStream_t stream);
+
 int vc_conv_wgrad(const int* desc, int dtype, const void* x, int ldx, const void* dy, int lddy, float* dw_packed,
-                  int force_naive, hipStream_t stream) {
+                  float* dbias, int force_naive, hipStream_t stream) {
   ConvGeom g;
   int rc = fill_geom(g, desc, 0, "vc_conv_wgrad");
   if (rc) return rc;
@@ -1454,6 +1478,7 @@ int vc_conv_wgrad(const int* desc, int dtype, const void* x, int ldx, const void
   if (dtype == VC_BF16 && !force_naive) {
     VC_CHECK_SHAPE(g.Ci % 8 == 0 && g.Co % 8 == 0, "vc_conv_wgrad: bf16 path needs Ci %% 8 == 0 and Co %% 8 == 0");
     const bool fast = use_glds() && !use_generic_nt();
+    float* dbias_fused = fast ? dbias : nullptr;
     int tco = (fast && g.Co <= 64 && wgrad_narrow()) ? 64 : 128;
     int tcol = (fast && g.K <= 64 && wgrad_narrow()) ? 64 : 128;
     // measured on the ResNet-50 shapes: short pixel ranges (late stages) and wide 1x1 layers run 5-15% faster
@@ -1475,16 +1500,16 @@ int vc_conv_wgrad(const int* desc, int dtype, const void* x, int ldx, const void
     const dim3 grid(ntiles * splits);
     if (fast && tco == 64 && tcol == 64)
       hipLaunchKernelGGL((igemm_tn_wgrad_fast_kernel<64, 64>), grid, dim3(NTHR), 0, stream, g, (const bf16*)x,
-                         (const bf16*)dy, ldy_, dw_packed, mps, ntiles, tiles_col);
+                         (const bf16*)dy, ldy_, dw_packed, mps, ntiles, tiles_col, dbias_fused);
     else if (fast && tco == 64)
       hipLaunchKernelGGL((igemm_tn_wgrad_fast_kernel<64, 128>), grid, dim3(NTHR), 0, stream, g, (const bf16*)x,
-                         (const bf16*)dy, ldy_, dw_packed, mps, ntiles, tiles_col);
+                         (const bf16*)dy, ldy_, dw_packed, mps, ntiles, tiles_col, dbias_fused);
     else if (fast && tcol == 64)
       hipLaunchKernelGGL((igemm_tn_wgrad_fast_kernel<128, 64>), grid, dim3(NTHR), 0, stream, g, (const bf16*)x,
-                         (const bf16*)dy, ldy_, dw_packed, mps, ntiles, tiles_col);
+                         (const bf16*)dy, ldy_, dw_packed, mps, ntiles, tiles_col, dbias_fused);
     else if (fast)
       hipLaunchKernelGGL((igemm_tn_wgrad_fast_kernel<128, 128>), grid, dim3(NTHR), 0, stream, g, (const bf16*)x,
-                         (const bf16*)dy, ldy_, dw_packed, mps, ntiles, tiles_col);
+                         (const bf16*)dy, ldy_, dw_packed, mps, ntiles, tiles_col, dbias_fused);
     else if (use_glds())
       hipLaunchKernelGGL((igemm_tn_wgrad_bf16_kernel<true>), dim3(ntiles * splits), dim3(NTHR), 0, stream, g,
                          (const bf16*)x, (const bf16*)dy, ldy_, dw_packed, mps, ntiles, tiles_col);
@@ -1504,6 +1529,9 @@ int vc_conv_wgrad(const int* desc, int dtype, const void* x, int ldx, const void
     return VC_ERR_DTYPE;
   }
   VC_LAUNCH_CHECK("vc_conv_wgrad");
+  // bias gradient: fused into the MFMA kernel above where that ran, a column-sum pass over dy otherwise
+  const bool fused = dtype == VC_BF16 && !force_naive && use_glds() && !use_generic_nt();
+  if (dbias && !fused) return vc_colsum(dtype, dy, dbias, g.M, g.Co, ldy_, stream);
   return VC_OK;
 }
 

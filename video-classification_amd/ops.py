@@ -253,20 +253,27 @@ class _Conv(torch.autograd.Function):
             dy = elementwise(1, dy, cast(y, dtype))
         desc = L.int_array(ctx.desc)
         weight, bias = ctx.weight, ctx.bias
+        # the bias gradient (column sums of dy) rides along with the weight-gradient pass over dy
+        want_db = bias is not None and bias.requires_grad
+        dbp = None
+        if want_db:
+            dbp = _grad_buf(bias) if cop == co else _zero_scratch(None, "", (cop,), x.device)
         if weight.requires_grad:
             if ctx.taps == 1 and cip == ci and cop == co:
                 # the packed layout IS the parameter's layout: accumulate straight into the gradient
                 dwp = _grad_buf(weight)
                 _timed("conv_wgrad", ctx.flops, lambda: L.call(
-                    "vc_conv_wgrad", desc, code, L.ptr(x), 0, L.ptr(dy), 0, L.ptr(dwp), 0, L.stream()))
+                    "vc_conv_wgrad", desc, code, L.ptr(x), 0, L.ptr(dy), 0, L.ptr(dwp), L.ptr(dbp), 0, L.stream()))
             else:
                 dwp = _wgrad_scratch(weight, (cop, ctx.taps, cip))
                 _timed("conv_wgrad", ctx.flops, lambda: L.call(
-                    "vc_conv_wgrad", desc, code, L.ptr(x), 0, L.ptr(dy), 0, L.ptr(dwp), 0, L.stream()))
+                    "vc_conv_wgrad", desc, code, L.ptr(x), 0, L.ptr(dy), 0, L.ptr(dwp), L.ptr(dbp), 0, L.stream()))
                 L.call("vc_unpack_wgrad", L.ptr(dwp), L.ptr(_grad_buf(weight)), co, ci, ctx.taps, cip, 3, L.stream())
-        if bias is not None and bias.requires_grad:
+        elif want_db:
             M = dy.numel() // cop
-            L.call("vc_colsum", code, L.ptr(dy), L.ptr(_grad_buf(bias)), M, co, cop, L.stream())
+            L.call("vc_colsum", code, L.ptr(dy), L.ptr(dbp), M, cop, cop, L.stream())
+        if want_db and cop != co:  # padded channel count: fold the first co sums into the parameter's gradient
+            _grad_buf(bias).add_(dbp[:co])
         _ready(weight, bias)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -670,14 +677,14 @@ class _LSTM(torch.autograd.Function):
                 if w_ih.requires_grad:
                     # a Linear weight's packed gradient layout is the parameter's own: accumulate in place
                     L.call("vc_conv_wgrad", _lin_desc(T * B, Kin, 4 * H), code, L.ptr(inp), 0, L.ptr(dg), 0,
-                           L.ptr(_grad_buf(w_ih)), 0, st)
+                           L.ptr(_grad_buf(w_ih)), L.ptr(None), 0, st)
                 if w_hh.requires_grad and T > 1:
                     # pairs (h_prev, dgates_t): forward dir h[0..T-2] with dg[1..T-1]; reverse dir h[1..T-1] with dg[0..T-2]
                     h_off = 0 if d == 0 else 1
                     g_off = 1 if d == 0 else 0
                     L.call("vc_conv_wgrad", _lin_desc((T - 1) * B, H, 4 * H), code,
                            _off(out, (h_off * B) * H * dirs + d * H), H * dirs, _off(dg, g_off * B * 4 * H), 0,
-                           L.ptr(_grad_buf(w_hh)), 0, st)
+                           L.ptr(_grad_buf(w_hh)), L.ptr(None), 0, st)
                 for b_ in (b_ih, b_hh):
                     if b_.requires_grad:
                         L.call("vc_colsum", code, L.ptr(dg), L.ptr(_grad_buf(b_)), T * B, 4 * H, 4 * H, st)
@@ -922,8 +929,9 @@ class _TCGFuse(torch.autograd.Function):
         desc = _lin_desc(T * B, 4 * H, 2 * H)
         gw, gb = ctx.gate_w, ctx.gate_b
         if gw.requires_grad:
-            L.call("vc_conv_wgrad", desc, code, L.ptr(cat), 0, L.ptr(dz), 0, L.ptr(_grad_buf(gw)), 0, st)
-        if gb.requires_grad:
+            L.call("vc_conv_wgrad", desc, code, L.ptr(cat), 0, L.ptr(dz), 0, L.ptr(_grad_buf(gw)),
+                   L.ptr(_grad_buf(gb) if gb.requires_grad else None), 0, st)
+        elif gb.requires_grad:
             L.call("vc_colsum", code, L.ptr(dz), L.ptr(_grad_buf(gb)), T * B, 2 * H, 2 * H, st)
         _ready(gw, gb)
         dcat = torch.empty(T, B, 4 * H, device=dev, dtype=dt)
