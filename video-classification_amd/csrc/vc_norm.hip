@@ -388,35 +388,51 @@ __global__ void bn_bwd_params_kernel(float* __restrict__ s1, float* __restrict__
 }
 
 // ------------------------------ LayerNorm ---------------------------------
-// one wave per row; C % 8 == 0; saves mean and rstd per row
-template <typename T>
-__global__ void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-                              T* __restrict__ out, float* __restrict__ mean, float* __restrict__ rstd, int M, int C,
-                              float eps) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (row >= M) return;
+// A row is handled by LPR lanes (16, 32 or 64 = one wave), so that narrow rows (Swin stage 1: C = 96 = 12
+// 16-byte chunks) still keep most lanes busy: a wave normalises 64/LPR rows at once.  C % 8 == 0.
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <typename T, int LPR>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, T* __restrict__ out,
+                                                      float* __restrict__ mean, float* __restrict__ rstd, int M, int C,
+                                                      float eps) {
+  constexpr int RPB = 256 / LPR;  // rows per block
+  const int sub = threadIdx.x % LPR;
+  const int row = blockIdx.x * RPB + threadIdx.x / LPR;
+  const bool live = row < M;      // dead rows still take part in the shuffles
   const int C8 = C >> 3;
-  const T* xr = x + (size_t)row * C;
-  float s = 0.f;
-  for (int cc = lane; cc < C8; cc += 64) {
+  const T* xr = x + (size_t)(live ? row : 0) * C;
+  float s = 0.f, q = 0.f;
+  for (int cc = sub; cc < C8; cc += LPR) {
     const F8 v = load8(xr + cc * 8);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s += v.v[i];
+    for (int i = 0; i < 8; ++i) {
+      s += v.v[i];
+      q = fmaf(v.v[i], v.v[i], q);
+    }
   }
-  const float mu = wave_sum(s) / C;
-  float q = 0.f;
-  for (int cc = lane; cc < C8; cc += 64) {
+  const float mu = group_sum<LPR>(s) / C;
+  // two-pass variance on the values just read (they are in cache): exact for constant rows
+  float d2 = 0.f;
+  for (int cc = sub; cc < C8; cc += LPR) {
     const F8 v = load8(xr + cc * 8);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) q = fmaf(v.v[i] - mu, v.v[i] - mu, q);
+    for (int i = 0; i < 8; ++i) d2 = fmaf(v.v[i] - mu, v.v[i] - mu, d2);
   }
-  const float rs = rsqrtf(wave_sum(q) / C + eps);
-  if (lane == 0) {
+  const float rs = rsqrtf(group_sum<LPR>(d2) / C + eps);
+  (void)q;
+  if (!live) return;
+  if (sub == 0) {
     mean[row] = mu;
     rstd[row] = rs;
   }
-  for (int cc = lane; cc < C8; cc += 64) {
+  for (int cc = sub; cc < C8; cc += LPR) {
     const F8 v = load8(xr + cc * 8), ga = load8(gamma + cc * 8), be = load8(beta + cc * 8);
     F8 o;
 #pragma unroll
@@ -425,66 +441,76 @@ __global__ void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__
   }
 }
 
-// dx per row; dgamma/dbeta partial sums accumulated with atomics per block
-template <typename T>
-__global__ void ln_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dout, const float* __restrict__ gamma,
-                              const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dx,
-                              float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int C,
-                              int rows_per_block) {
+// dx per row; dgamma/dbeta: per-thread partial sums over the rows the thread sees (its channel chunks are
+// fixed), folded in LDS per block and added to global memory with one atomic per channel and block.
+// NCH = channel chunks per lane (C8 <= LPR * NCH).
+template <typename T, int LPR, int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dout,
+                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd, T* __restrict__ dx,
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int M,
+                                                      int C, int rows_per_block) {
   extern __shared__ float lds[];  // [2][C]
+  constexpr int RPB = 256 / LPR;
   const int C8 = C >> 3;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int sub = threadIdx.x % LPR, rsl = threadIdx.x / LPR;
   for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) lds[i] = 0.f;
   __syncthreads();
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(M, r0 + rows_per_block);
-  // per-lane partial dgamma/dbeta live in registers for the channels this lane owns
-  // (C <= 64*8*4 = 2048 supported per lane with 4 chunks)
-  float pg[4][8], pb[4][8];
+  float pg[NCH][8], pb[NCH][8];
+  F8 ga[NCH];
 #pragma unroll
-  for (int k = 0; k < 4; ++k)
+  for (int k = 0; k < NCH; ++k) {
+    const int cc = sub + LPR * k;
 #pragma unroll
     for (int i = 0; i < 8; ++i) pg[k][i] = pb[k][i] = 0.f;
-  for (int row = r0 + wave; row < r1; row += nw) {
-    const T* xr = x + (size_t)row * C;
-    const T* dr = dout + (size_t)row * C;
-    const float mu = mean[row], rs = rstd[row];
+    if (cc < C8) ga[k] = load8(gamma + cc * 8);
+  }
+  for (int rb = r0; rb < r1; rb += RPB) {  // uniform trip count: every lane joins the shuffles
+    const int row = rb + rsl;
+    const bool live = row < r1;
+    const size_t ro = (size_t)(live ? row : r0) * C;
+    const float mu = mean[live ? row : r0], rs = rstd[live ? row : r0];
+    F8 xv[NCH], dv[NCH];
     float a = 0.f, b = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int cc = lane + 64 * k;
+    for (int k = 0; k < NCH; ++k) {
+      const int cc = sub + LPR * k;
       if (cc < C8) {
-        const F8 v = load8(xr + cc * 8), d = load8(dr + cc * 8), ga = load8(gamma + cc * 8);
+        xv[k] = load8(x + ro + cc * 8);
+        dv[k] = load8(dout + ro + cc * 8);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const float xh = (v.v[i] - mu) * rs, dg = d.v[i] * ga.v[i];
+          const float xh = (xv[k].v[i] - mu) * rs, dg = dv[k].v[i] * ga[k].v[i];
+          xv[k].v[i] = xh;
           a += dg;
           b = fmaf(dg, xh, b);
-          pg[k][i] = fmaf(d.v[i], xh, pg[k][i]);
-          pb[k][i] += d.v[i];
+          if (live) {
+            pg[k][i] = fmaf(dv[k].v[i], xh, pg[k][i]);
+            pb[k][i] += dv[k].v[i];
+          }
         }
       }
     }
-    a = wave_sum(a) / C;
-    b = wave_sum(b) / C;
+    a = group_sum<LPR>(a) / C;
+    b = group_sum<LPR>(b) / C;
+    if (live) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int cc = lane + 64 * k;
-      if (cc < C8) {
-        const F8 v = load8(xr + cc * 8), d = load8(dr + cc * 8), ga = load8(gamma + cc * 8);
-        F8 o;
+      for (int k = 0; k < NCH; ++k) {
+        const int cc = sub + LPR * k;
+        if (cc < C8) {
+          F8 o;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float xh = (v.v[i] - mu) * rs;
-          o.v[i] = rs * (d.v[i] * ga.v[i] - a - xh * b);
+          for (int i = 0; i < 8; ++i) o.v[i] = rs * (dv[k].v[i] * ga[k].v[i] - a - xv[k].v[i] * b);
+          store8(dx + ro + cc * 8, o);
         }
-        store8(dx + (size_t)row * C + cc * 8, o);
       }
     }
   }
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int cc = lane + 64 * k;
+  for (int k = 0; k < NCH; ++k) {
+    const int cc = sub + LPR * k;
     if (cc < C8) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -653,14 +679,17 @@ int vc_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* 
                      float* rstd, int M, int C, float eps, hipStream_t stream) {
   VC_CHECK_ARG(x && gamma && beta && out && mean && rstd, "vc_layernorm_fwd: null pointer");
   VC_CHECK_SHAPE(C % 8 == 0 && M > 0, "vc_layernorm_fwd: need C %% 8 == 0 (C=%d)", C);
-  dim3 grid(ceil_div(M, 4));
-  if (dtype == VC_BF16)
-    hipLaunchKernelGGL((ln_fwd_kernel<bf16>), grid, dim3(256), 0, stream, (const bf16*)x, gamma, beta, (bf16*)out,
-                       mean, rstd, M, C, eps);
-  else if (dtype == VC_F32)
-    hipLaunchKernelGGL((ln_fwd_kernel<float>), grid, dim3(256), 0, stream, (const float*)x, gamma, beta, (float*)out,
-                       mean, rstd, M, C, eps);
-  else { vc_set_error("vc_layernorm_fwd: unsupported dtype %d", dtype); return VC_ERR_DTYPE; }
+  const int lpr = C <= 128 ? 16 : (C <= 256 ? 32 : 64);
+  dim3 grid(ceil_div(M, 256 / lpr));
+#define VC_LN_FWD(T, LPR)                                                                                        \
+  hipLaunchKernelGGL((ln_fwd_kernel<T, LPR>), grid, dim3(256), 0, stream, (const T*)x, gamma, beta, (T*)out, mean, \
+                     rstd, M, C, eps)
+  if (dtype == VC_BF16) {
+    if (lpr == 16) VC_LN_FWD(bf16, 16); else if (lpr == 32) VC_LN_FWD(bf16, 32); else VC_LN_FWD(bf16, 64);
+  } else if (dtype == VC_F32) {
+    if (lpr == 16) VC_LN_FWD(float, 16); else if (lpr == 32) VC_LN_FWD(float, 32); else VC_LN_FWD(float, 64);
+  } else { vc_set_error("vc_layernorm_fwd: unsupported dtype %d", dtype); return VC_ERR_DTYPE; }
+#undef VC_LN_FWD
   VC_LAUNCH_CHECK("vc_layernorm_fwd");
   return VC_OK;
 }
@@ -670,17 +699,26 @@ int vc_layernorm_bwd(int dtype, const void* x, const void* dout, const float* ga
                      const float* rstd, void* dx, float* dgamma, float* dbeta, int M, int C, hipStream_t stream) {
   VC_CHECK_ARG(x && dout && gamma && mean && rstd && dx && dgamma && dbeta, "vc_layernorm_bwd: null pointer");
   VC_CHECK_SHAPE(C % 8 == 0 && C <= 2048 && M > 0, "vc_layernorm_bwd: need C %% 8 == 0 and C <= 2048 (C=%d)", C);
+  // lanes per row / chunks per lane: (16,1) C<=128, (32,1) C<=256, (64,1) C<=512, (64,2) C<=1024, (64,4) C<=2048
+  const int lpr = C <= 128 ? 16 : (C <= 256 ? 32 : 64);
   int rows_per_block = 64;
   while (ceil_div(M, rows_per_block) > 1024) rows_per_block *= 2;
   dim3 grid(ceil_div(M, rows_per_block));
   const size_t lds = 2 * (size_t)C * sizeof(float);
-  if (dtype == VC_BF16)
-    hipLaunchKernelGGL((ln_bwd_kernel<bf16>), grid, dim3(256), lds, stream, (const bf16*)x, (const bf16*)dout, gamma,
-                       mean, rstd, (bf16*)dx, dgamma, dbeta, M, C, rows_per_block);
-  else if (dtype == VC_F32)
-    hipLaunchKernelGGL((ln_bwd_kernel<float>), grid, dim3(256), lds, stream, (const float*)x, (const float*)dout,
-                       gamma, mean, rstd, (float*)dx, dgamma, dbeta, M, C, rows_per_block);
+#define VC_LN_BWD(T, LPR, NCH)                                                                                  \
+  hipLaunchKernelGGL((ln_bwd_kernel<T, LPR, NCH>), grid, dim3(256), lds, stream, (const T*)x, (const T*)dout,   \
+                     gamma, mean, rstd, (T*)dx, dgamma, dbeta, M, C, rows_per_block)
+#define VC_LN_BWD_ALL(T)                                       \
+  if (lpr == 16) VC_LN_BWD(T, 16, 1);                          \
+  else if (lpr == 32) VC_LN_BWD(T, 32, 1);                     \
+  else if (C <= 512) VC_LN_BWD(T, 64, 1);                      \
+  else if (C <= 1024) VC_LN_BWD(T, 64, 2);                     \
+  else VC_LN_BWD(T, 64, 4)
+  if (dtype == VC_BF16) { VC_LN_BWD_ALL(bf16); }
+  else if (dtype == VC_F32) { VC_LN_BWD_ALL(float); }
   else { vc_set_error("vc_layernorm_bwd: unsupported dtype %d", dtype); return VC_ERR_DTYPE; }
+#undef VC_LN_BWD_ALL
+#undef VC_LN_BWD
   VC_LAUNCH_CHECK("vc_layernorm_bwd");
   return VC_OK;
 }
