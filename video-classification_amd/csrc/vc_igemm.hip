@@ -607,8 +607,11 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
 
   const int lrow = tid >> 3, pchunk = tid & 7;
   const int lchunk = pchunk ^ ((lrow >> 1) & 7);
-  const int ncb = g.Ci / BK;  // k-tiles per tap
-  const int nk = g.K / BK;    // k-tiles per output tile (>= 1)
+  // k-tiles per tap; a single-tap layer (linear, 1x1 convolution) may have any channel count that is a
+  // multiple of 8: the chunks of its last k-tile that lie beyond Ci read the zero page
+  const int ncb = (g.Ci + BK - 1) / BK;
+  const int nk = g.kd * g.kh * g.kw * ncb;  // k-tiles per output tile (>= 1)
+  const bool ktail = (g.Ci % BK) != 0;
   const bf16* zero = reinterpret_cast<const bf16*>(vc_zero_src);
 
   // staging state (runs one k-tile ahead of the multiply)
@@ -656,16 +659,21 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
     }
     bf16* sA = smem + buf * (BM + TN_) * BK;
     bf16* sW = sA + BM * BK;
+    if (ktail && cb * BK + lchunk * 8 >= g.Ci) {  // this thread's chunk of a partial last k-tile
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      glds16(ap[i], sA + (32 * i + 8 * wave) * BK);
-      ap[i] += ainc[i];
+      for (int i = 0; i < 4; ++i) glds16(zero, sA + (32 * i + 8 * wave) * BK);
+#pragma unroll
+      for (int i = 0; i < NWROW; ++i) glds16(zero, sW + (32 * i + 8 * wave) * BK);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) glds16(ap[i], sA + (32 * i + 8 * wave) * BK);
+#pragma unroll
+      for (int i = 0; i < NWROW; ++i) glds16(wp[i], sW + (32 * i + 8 * wave) * BK);
     }
 #pragma unroll
-    for (int i = 0; i < NWROW; ++i) {
-      glds16(wp[i], sW + (32 * i + 8 * wave) * BK);
-      wp[i] += winc[i];
-    }
+    for (int i = 0; i < 4; ++i) ap[i] += ainc[i];
+#pragma unroll
+    for (int i = 0; i < NWROW; ++i) wp[i] += winc[i];
     if (++cb == ncb) {
       cb = 0;
       ++tap;
@@ -1338,7 +1346,9 @@ int wgrad_target_blocks() {
 }
 
 bool nt_persist_eligible(const ConvGeom& g, int dtype) {
-  return dtype == VC_BF16 && use_glds() && g.Ci % BK == 0 && g.ldi % 8 == 0 && g.K >= BK && nt_variant() == 2;
+  const bool single_tap = g.kd * g.kh * g.kw == 1;
+  return dtype == VC_BF16 && use_glds() && g.ldi % 8 == 0 && g.K >= 8 && nt_variant() == 2 &&
+         (g.Ci % BK == 0 || (single_tap && g.Ci % 8 == 0));
 }
 
 template <int MODE>
