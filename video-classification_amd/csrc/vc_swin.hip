@@ -543,17 +543,18 @@ __global__ __launch_bounds__(64 * AW) void window_attn_fwd_mfma_kernel(SwinGeom 
   }
 }
 
-// grid = (window chunks, heads); each wave walks `wpw` windows of one head and accumulates the bias gradient of
-// its windows in a per-wave LDS matrix [i][j] (every (i, j) is owned by exactly one lane register, so the LDS
-// adds never collide), flushed to the table with one atomic per (i, j) at the end.
-__global__ __launch_bounds__(64 * AW, 1) void window_attn_bwd_mfma_kernel(SwinGeom g, const bf16* __restrict__ qkv,
+// grid = (window chunks, heads); each wave walks `wpw` windows of one head.  Everything that does not depend on
+// the window is hoisted into registers before the walk: the relative-position bias (plus the -inf of the padded
+// keys) of the 64 (i, j) elements a lane owns in either orientation, and the bias-gradient accumulator of the
+// 64 elements it owns in the first orientation, which is folded onto the (2ws-1)^2 bins once, after the walk.
+// Per window only the shift-mask regions are looked up (20 + 20 LDS reads per lane instead of ~6 per element).
+__global__ __launch_bounds__(64 * AW, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void window_attn_bwd_mfma_kernel(SwinGeom g, const bf16* __restrict__ qkv,
                                                                            const bf16* __restrict__ dout,
                                                                            const float* __restrict__ bias_table,
                                                                            bf16* __restrict__ dqkv,
                                                                            float* __restrict__ dbias_table,
                                                                            float scale, int windows_total, int wpw) {
   __shared__ __attribute__((aligned(16))) bf16 sT[AW][4][TS];   // q, k, v, dO tiles per wave
-  __shared__ float sDB[AW][MAXN * MAXN];
   __shared__ float sBias[AW][176];
   __shared__ float sBin[176];
   __shared__ int sReg[AW][64];
@@ -561,14 +562,37 @@ __global__ __launch_bounds__(64 * AW, 1) void window_attn_bwd_mfma_kernel(SwinGe
   __shared__ int sRC[64];
   __shared__ float sMax[AW][64], sInv[AW][64], sDot[AW][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int gq = lane >> 4;
+  const int gq = lane >> 4, l15 = lane & 15;
   const int N = g.ws * g.ws;
   const int head = blockIdx.y;
   const int nb = (2 * g.ws - 1) * (2 * g.ws - 1);
+  const int off = (g.ws - 1) * (2 * g.ws);
   if (threadIdx.x < 64) sRC[threadIdx.x] = (threadIdx.x / g.ws) * (2 * g.ws - 1) + (threadIdx.x % g.ws);
   if (threadIdx.x < 176) sBin[threadIdx.x] = 0.f;
   for (int k = lane; k < nb; k += 64) sBias[wave][k] = bias_table[k * g.heads + head];
-  for (int k = lane; k < MAXN * MAXN; k += 64) sDB[wave][k] = 0.f;
+  __syncthreads();
+
+  // orientation 1: element (ti, tj, r) = (query i = 16ti + l15, key j = 16tj + 4gq + r)
+  // orientation 2: element (ti, r, tj) = (query i = 16ti + 4gq + r, key j = 16tj + l15)
+  float bt1[4][4][4], bt2[4][4][4], dbacc[4][4][4];
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        {
+          const int i = 16 * ti + l15, j = 16 * tj + 4 * gq + r;
+          const int ic = i < N ? i : N - 1;
+          bt1[ti][tj][r] = j < N ? sBias[wave][sRC[ic] - sRC[j] + off] : -INFINITY;
+        }
+        {
+          const int i = 16 * ti + 4 * gq + r, j = 16 * tj + l15;
+          const int ic = i < N ? i : N - 1;
+          bt2[ti][r][tj] = j < N ? sBias[wave][sRC[ic] - sRC[j] + off] : -INFINITY;
+        }
+        dbacc[ti][tj][r] = 0.f;
+      }
 
   const int w_first = (blockIdx.x * AW + wave) * wpw;
   for (int it = 0; it < wpw; ++it) {
@@ -599,6 +623,24 @@ __global__ __launch_bounds__(64 * AW, 1) void window_attn_bwd_mfma_kernel(SwinGe
     const bf16* tK = sT[wave][1];
     const bf16* tV = sT[wave][2];
     const bf16* tD = sT[wave][3];
+    // shift-mask regions of this window for the elements the lane owns (padded tokens take token N-1's)
+    int ri1[4], rj1[4][4], ri2[4][4], rj2[4];
+    if (g.shift) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int i1 = 16 * t + l15;
+        ri1[t] = sReg[wave][i1 < N ? i1 : N - 1];
+        const int j2 = 16 * t + l15;
+        rj2[t] = sReg[wave][j2 < N ? j2 : N - 1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int x = 16 * t + 4 * gq + r;
+          const int v = sReg[wave][x < N ? x : N - 1];
+          rj1[t][r] = v;
+          ri2[t][r] = v;
+        }
+      }
+    }
 
     // ---- orientation 1: rows j, columns i (lane <-> query i); one column tile ti at a time ------------
     f32x4 dq[2][4];
@@ -608,7 +650,7 @@ __global__ __launch_bounds__(64 * AW, 1) void window_attn_bwd_mfma_kernel(SwinGe
       for (int ti = 0; ti < 4; ++ti) dq[te][ti] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti) {
-      const int i = 16 * ti + (lane & 15);
+      const int i = 16 * ti + l15;
       const bf16x8 qf = frag_rows(tQ, ti, lane), df = frag_rows(tD, ti, lane);
       f32x4 st[4], dp[4];
 #pragma unroll
@@ -621,8 +663,8 @@ __global__ __launch_bounds__(64 * AW, 1) void window_attn_bwd_mfma_kernel(SwinGe
       for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float sc = score_of<true>(st[tj][r], 16 * tj + 4 * gq + r, i, N, g.ws, sBias[wave], sReg[wave], sRC,
-                                          g.shift, scale);
+          float sc = fmaf(st[tj][r], scale, bt1[ti][tj][r]);
+          if (g.shift && ri1[ti] != rj1[tj][r]) sc -= 100.f;
           st[tj][r] = sc;
           mx = fmaxf(mx, sc);
         }
@@ -655,15 +697,14 @@ __global__ __launch_bounds__(64 * AW, 1) void window_attn_bwd_mfma_kernel(SwinGe
         sInv[wave][i] = inv;
         sDot[wave][i] = dot;
       }
-      const bool ivalid = (i < N) && uvalid;
+      const float live = ((i < N) && uvalid) ? 1.f : 0.f;  // padded queries / windows add nothing to the bias
 #pragma unroll
       for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float ds = st[tj][r] * (dp[tj][r] - dot);  // dS^T (zero where P is zero: j >= N)
           st[tj][r] = ds;
-          const int j = 16 * tj + 4 * gq + r;
-          if (ivalid && j < N) atomicAdd(&sDB[wave][i * MAXN + j], ds);
+          dbacc[ti][tj][r] = fmaf(live, ds, dbacc[ti][tj][r]);
         }
       // dQ^T[e][i] += sum_j K^T[e][j] dS^T[j][i]
 #pragma unroll
@@ -677,7 +718,7 @@ __global__ __launch_bounds__(64 * AW, 1) void window_attn_bwd_mfma_kernel(SwinGe
     if (uvalid) {
 #pragma unroll
       for (int ti = 0; ti < 4; ++ti) {
-        const int i = 16 * ti + (lane & 15);
+        const int i = 16 * ti + l15;
         if (i >= N) continue;
         bf16* drow = dqkv + (size_t)sTok[wave][i] * 3 * g.C + head * HD;
 #pragma unroll
@@ -711,12 +752,13 @@ __global__ __launch_bounds__(64 * AW, 1) void window_attn_bwd_mfma_kernel(SwinGe
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = 16 * ti + 4 * gq + r;
-          const float mx = sMax[wave][i], inv = sInv[wave][i], dot = sDot[wave][i];
+          const float mx = sMax[wave][i], dot = sDot[wave][i];
+          const float inv = (i < N) ? sInv[wave][i] : 0.f;  // padded queries contribute nothing
 #pragma unroll
           for (int tj = 0; tj < 4; ++tj) {
-            const int j = 16 * tj + (lane & 15);
-            const float sc = score_of<false>(st[h][tj][r], i, j, N, g.ws, sBias[wave], sReg[wave], sRC, g.shift, scale);
-            const float p = (i < N) ? __expf(sc - mx) * inv : 0.f;  // P[i][j]; padded queries contribute nothing
+            float sc = fmaf(st[h][tj][r], scale, bt2[ti][r][tj]);
+            if (g.shift && ri2[ti][r] != rj2[tj]) sc -= 100.f;
+            const float p = __expf(sc - mx) * inv;  // P[i][j]
             st[h][tj][r] = p;
             dp[h][tj][r] = p * (dp[h][tj][r] - dot);                // dS[i][j]
           }
@@ -736,7 +778,7 @@ __global__ __launch_bounds__(64 * AW, 1) void window_attn_bwd_mfma_kernel(SwinGe
     if (uvalid) {
 #pragma unroll
       for (int tj = 0; tj < 4; ++tj) {
-        const int j = 16 * tj + (lane & 15);
+        const int j = 16 * tj + l15;
         if (j >= N) continue;
         bf16* drow = dqkv + (size_t)sTok[wave][j] * 3 * g.C + head * HD;
 #pragma unroll
@@ -755,10 +797,17 @@ __global__ __launch_bounds__(64 * AW, 1) void window_attn_bwd_mfma_kernel(SwinGe
   }
   __syncthreads();
   if (dbias_table) {
-    // fold the [i][j] matrix onto the (2ws-1)^2 relative-position bins in LDS, then one global atomic per bin
-    const int off = (g.ws - 1) * (2 * g.ws);
-    for (int i = 0; i < N; ++i)
-      if (lane < N) atomicAdd(&sBin[sRC[i] - sRC[lane] + off], sDB[wave][i * MAXN + lane]);
+    // fold the lane-owned (i, j) sums onto the (2ws-1)^2 relative-position bins in LDS, then one global atomic
+    // per bin and block
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * ti + l15, j = 16 * tj + 4 * gq + r;
+          if (i < N && j < N) atomicAdd(&sBin[sRC[i] - sRC[j] + off], dbacc[ti][tj][r]);
+        }
     __syncthreads();
     if ((int)threadIdx.x < nb) atomicAdd(dbias_table + threadIdx.x * g.heads + head, sBin[threadIdx.x]);
   }
