@@ -105,6 +105,12 @@ def cpu_baseline(args):
             "sample": f"{n} training steps of {b} clips {tuple(shape[1:])} after 1 warm-up, fp32, same architecture"}
 
 
+def trace(msg):
+    """Progress marks on stderr (VC_BENCH_TRACE=1): where a multi-rank run is, should it stall."""
+    if os.environ.get("VC_BENCH_TRACE", "0") == "1":
+        print(f"[bench rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,6 +138,10 @@ def main():
     from video_classification_amd import trainer as TR
 
     rank, local_rank, world = TR.init_distributed()
+    trace(f"distributed initialised: world {world}")
+    if os.environ.get("VC_BENCH_TRACE", "0") == "1":
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ.get("VC_BENCH_TRACE_AFTER", "90")), exit=False)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU with torch.distributed.run")
     if not torch.cuda.is_available():
@@ -144,7 +154,9 @@ def main():
     model, shape, workload = build_workload(args, M, S)
     model = model.to(dev).set_compute_dtype(dt)
     opt = TR.get_optimizer(model, "adam", lr=1e-4, weight_decay=1e-4)
+    trace("model and optimizer built")
     TR.make_data_parallel(model, opt, bucket_mb=args.bucket_mb)
+    trace("parameters broadcast")
     crit = TR.FusedCrossEntropyLoss()
     ops.manual_seed(1234 + rank)
     g = torch.Generator().manual_seed(1234 + rank)
@@ -180,8 +192,10 @@ def main():
         except Exception as exc:  # pragma: no cover - depends on the runtime
             print(f"[bench] graph capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
             torch.cuda.synchronize()
+    trace(f"step executor: {mode}")
     for _ in range(args.warmup):
         step()
+    trace("warm-up done")
 
     if mode == "eager":
         ops.PROFILE = []
@@ -191,6 +205,7 @@ def main():
         loss = step()
     fence()
     elapsed = time.perf_counter() - t0
+    trace("timed region done")
     prof_steps = args.steps
     if mode == "eager":
         prof, ops.PROFILE = ops.PROFILE, None

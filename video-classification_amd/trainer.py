@@ -232,6 +232,12 @@ class GradBucketer:
             return
         lo, hi = self.buckets[b]
         view = self.flat.grad[lo:hi]
+        if self.on_gpu and dist.get_backend(self.group) == "gloo":
+            # rehearsal of the multi-rank flow on a box without RCCL peers: reduce a host copy, synchronously
+            host = view.detach().cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            view.copy_(host)
+            return
         if self.overlap:
             self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
@@ -258,6 +264,11 @@ def init_distributed(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal switches for a one-GPU box: every rank on device 0, collectives over gloo (RCCL refuses two
+    # ranks on one device)
+    if os.environ.get("VC_SINGLE_DEVICE", "0") == "1":
+        local_rank = 0
+    backend = backend or os.environ.get("VC_DIST_BACKEND") or None
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -277,8 +288,18 @@ def make_data_parallel(model, optimizer, bucket_mb=32, group=None, overlap=True)
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world > 1:
         dist.broadcast(flat.data, src=0, group=group)
+        # buffers (BatchNorm running statistics, counters): one broadcast per dtype instead of hundreds of tiny ones
+        by_dtype = {}
         for b in model.buffers():
-            dist.broadcast(b, src=0, group=group)
+            by_dtype.setdefault(b.dtype, []).append(b)
+        for bufs in by_dtype.values():
+            packed = torch.cat([b.detach().reshape(-1) for b in bufs])
+            dist.broadcast(packed, src=0, group=group)
+            o = 0
+            for b in bufs:
+                n = b.numel()
+                b.copy_(packed[o:o + n].view_as(b))
+                o += n
         ops.bump_weights_epoch()
     bucketer = GradBucketer(flat, bucket_bytes=bucket_mb << 20, group=group, overlap=overlap)
     optimizer.bucketer = bucketer
