@@ -518,8 +518,21 @@ __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[
   float ps[8], pq[8];  // per-channel sum / sum of squares of the values as stored (BatchNorm statistics)
 #pragma unroll
   for (int e = 0; e < 8; ++e) ps[e] = pq[e] = 0.f;
+  constexpr int NIT = 64 / RPI;
+  const bool vec = co + 7 < g.Co && (g.ldc & 7) == 0;
+  // beta: fetch everything the tile accumulates into up front (one memory latency, not one per row group)
+  bf16x8 oldv[NIT];
+  bf16* orow[NIT];
 #pragma unroll
-  for (int it = 0; it < 64 / RPI; ++it) {
+  for (int it = 0; it < NIT; ++it) {
+    const int m = m0 + wm * 64 + it * RPI + rr;
+    const bool live = m < g.M && co < g.Co;
+    orow[it] = live ? out + (size_t)(MODE == 2 ? phase_out_pixel(g, m) : m) * g.ldc + co : nullptr;
+    oldv[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (beta && live && vec) oldv[it] = *reinterpret_cast<const bf16x8*>(orow[it]);
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
     const int row = it * RPI + rr;
     const int m = m0 + wm * 64 + row;
     bf16x8 v = *reinterpret_cast<const bf16x8*>(stage_buf + row * WC + ((ch ^ (row & (NCH - 1))) << 3));
@@ -531,14 +544,13 @@ __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[
         pq[e] = fmaf(t, t, pq[e]);
       }
     }
-    if (m < g.M && co < g.Co) {
-      bf16* op = out + (size_t)(MODE == 2 ? phase_out_pixel(g, m) : m) * g.ldc + co;
-      if (co + 7 < g.Co && (g.ldc & 7) == 0) {
+    bf16* op = orow[it];
+    if (op) {
+      if (vec) {
         if (beta) {
-          const bf16x8 old = *reinterpret_cast<const bf16x8*>(op);
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            float t = (float)v[e] + (float)old[e];
+            float t = (float)v[e] + (float)oldv[it][e];
             if (relu) t = fmaxf(t, 0.f);
             v[e] = (bf16)t;
           }
