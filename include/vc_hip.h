@@ -116,6 +116,18 @@ int vc_layernorm_bwd(int dtype, const void* x, const void* dout, const float* ga
  * [B,1,T,H,W] from utils/common/data_loaders.py:56).  time_major: frame = t*B + b. */
 int vc_clip_to_channels_last(int dtype, const float* x, void* out, int B, int T, int C, int S, int Cp,
                              int time_major, int chan_outer, vc_stream_t stream);
+/* First layers with 1 or 3 input channels (ResNet stem models.resnet*.conv1 via model_components.py:164-165; EncoderCNN
+ * conv1 :84-88; Conv3D layer 1, UCF101_3DCNN_refactored.py:62-66; Swin patch_embed.proj): the kw taps along W are folded
+ * into the channel axis, out[f][h][wo][j*C + c] = x[.., c, h, wo*sw - pw + j] with Jp = pad8(kw*C) channels, so the
+ * layer runs as a (kd, kh, 1) convolution with stride (sd, sh, 1) instead of padding C to 8.  Frame order and source
+ * layouts as for vc_clip_to_channels_last.  vc_pack_weight_unfold / vc_unpack_wgrad_unfold convert the torch weight
+ * [co][ci][taps_outer][kw] to and from the matching packed form [co_pad][taps_outer][jp] (flags as vc_unpack_wgrad). */
+int vc_clip_unfold_w(int dtype, const float* x, void* out, int B, int T, int C, int H, int W, int kw, int sw, int pw,
+                     int Jp, int time_major, int chan_outer, vc_stream_t stream);
+int vc_pack_weight_unfold(int dtype, const float* w, void* w_fwd, int co, int ci, int taps_outer, int kw, int jp,
+                          int co_pad, vc_stream_t stream);
+int vc_unpack_wgrad_unfold(float* dw_packed, float* dw, int co, int ci, int taps_outer, int kw, int jp, int flags,
+                           vc_stream_t stream);
 /* nn.MaxPool2d(3,2,1) of the ResNet stem; nn.MaxPool3d((1,2,2)) (Conv3D :69,75,81,87) as a per-frame 2-D pool */
 int vc_maxpool2d_fwd(int dtype, const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, int k, int s, int p,
                      vc_stream_t stream);

@@ -1236,6 +1236,39 @@ __global__ void pack_weight_flat_t_kernel(const float* __restrict__ w, T* __rest
   wt[idx] = from_f32<T>((co < Co && c < Ci) ? w[((size_t)co * Ci + c) * taps + tap] : 0.f);
 }
 
+// Width-unfolded first layer: torch weight [Co][Ci][to][kw] (to = kd*kh outer taps)  ->  wf[Cop][to][Jp] with
+// channel index q = j*Ci + c (zero for q >= kw*Ci and for padded output channels)
+template <typename T>
+__global__ void pack_weight_unfold_kernel(const float* __restrict__ w, T* __restrict__ wf, int Co, int Ci, int to,
+                                          int kw, int Jp, int Cop) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)Cop * to * Jp) return;
+  const int q = (int)(idx % Jp);
+  const int t = (int)((idx / Jp) % to);
+  const int co = (int)(idx / ((int64_t)Jp * to));
+  float v = 0.f;
+  if (co < Co && q < kw * Ci) {
+    const int j = q / Ci, c = q - j * Ci;
+    v = w[(((size_t)co * Ci + c) * to + t) * kw + j];
+  }
+  wf[idx] = from_f32<T>(v);
+}
+
+// the inverse for the gradient: dw[co][c][t][j] (+)= dwp[co][t][j*Ci + c]; flags as for unpack_wgrad_kernel
+__global__ void unpack_wgrad_unfold_kernel(float* __restrict__ dwp, float* __restrict__ dw, int Co, int Ci, int to,
+                                           int kw, int Jp, int flags) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)Co * Ci * to * kw) return;
+  const int j = (int)(idx % kw);
+  const int t = (int)((idx / kw) % to);
+  const int c = (int)((idx / ((int64_t)kw * to)) % Ci);
+  const int co = (int)(idx / ((int64_t)kw * to * Ci));
+  const size_t src = ((size_t)co * to + t) * Jp + j * Ci + c;
+  const float v = dwp[src];
+  if (flags & 2) dwp[src] = 0.f;
+  dw[idx] = (flags & 1) ? dw[idx] + v : v;
+}
+
 // packed fp32 gradient [Co][taps][Cip] -> torch layout [Co][Ci][taps] (accumulating or not)
 // flags: bit 0 = add to dw instead of overwriting it, bit 1 = zero the packed source after reading it (a
 // caller-owned accumulator is then ready for the next weight-gradient launch without a fill pass)
@@ -1610,6 +1643,36 @@ int vc_pack_weight_flat_t(int dtype, const float* w, void* w_t, int co, int ci, 
     return VC_ERR_DTYPE;
   }
   VC_LAUNCH_CHECK("vc_pack_weight_flat_t");
+  return VC_OK;
+}
+
+int vc_pack_weight_unfold(int dtype, const float* w, void* w_fwd, int co, int ci, int taps_outer, int kw, int jp,
+                          int co_pad, hipStream_t stream) {
+  VC_CHECK_ARG(w && w_fwd, "vc_pack_weight_unfold: null pointer");
+  VC_CHECK_SHAPE(co > 0 && ci > 0 && taps_outer > 0 && kw > 0 && jp >= kw * ci && co_pad >= co,
+                 "vc_pack_weight_unfold: bad shape");
+  const int64_t total = (int64_t)co_pad * taps_outer * jp;
+  if (dtype == VC_BF16)
+    hipLaunchKernelGGL((pack_weight_unfold_kernel<bf16>), dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, stream,
+                       w, (bf16*)w_fwd, co, ci, taps_outer, kw, jp, co_pad);
+  else if (dtype == VC_F32)
+    hipLaunchKernelGGL((pack_weight_unfold_kernel<float>), dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0,
+                       stream, w, (float*)w_fwd, co, ci, taps_outer, kw, jp, co_pad);
+  else {
+    vc_set_error("vc_pack_weight_unfold: unsupported dtype %d", dtype);
+    return VC_ERR_DTYPE;
+  }
+  VC_LAUNCH_CHECK("vc_pack_weight_unfold");
+  return VC_OK;
+}
+
+int vc_unpack_wgrad_unfold(float* dw_packed, float* dw, int co, int ci, int taps_outer, int kw, int jp, int flags,
+                           hipStream_t stream) {
+  VC_CHECK_ARG(dw_packed && dw, "vc_unpack_wgrad_unfold: null pointer");
+  const int64_t total = (int64_t)co * ci * taps_outer * kw;
+  hipLaunchKernelGGL(unpack_wgrad_unfold_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, stream,
+                     dw_packed, dw, co, ci, taps_outer, kw, jp, flags);
+  VC_LAUNCH_CHECK("vc_unpack_wgrad_unfold");
   return VC_OK;
 }
 

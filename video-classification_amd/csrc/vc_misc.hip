@@ -46,6 +46,56 @@ __global__ void clip_to_cl_kernel(const float* __restrict__ x, T* __restrict__ o
 }
 
 // ---------------------------------------------------------------------------
+// Width-unfolded input of a network's first convolution (1 or 3 input channels): instead of padding the
+// channels to 8 (5/8 or 7/8 of every product wasted), the kw taps along W are folded into the channel axis,
+//   out[f][h][wo][j*C + c] = x[.., c, h, wo*sw - pw + j]      (zero outside the image and for j*C + c >= kw*C),
+// so the layer becomes a (kd, kh, 1) convolution with stride (sd, sh, 1) over Jp = pad8(kw*C) channels.
+// Source layouts and frame order as for clip_to_cl_kernel.
+// ---------------------------------------------------------------------------
+// One block per (frame, image row): the C source rows are read coalesced into LDS once, then every thread
+// assembles the Jp values of its output pixels from LDS and writes them as 16-byte vectors.
+template <typename T>
+__global__ void clip_unfold_w_kernel(const float* __restrict__ x, T* __restrict__ out, int B, int Tn, int C, int H,
+                                     int W, int Wo, int kw, int sw, int pw, int Jp, int time_major, int chan_outer) {
+  extern __shared__ float srow[];  // [C][W]
+  const int S = H * W;
+  const int fh = blockIdx.x;       // frame * H + h
+  const int h = fh % H, f = fh / H;
+  int b, t;
+  if (time_major) {
+    t = f / B;
+    b = f - t * B;
+  } else {
+    b = f / Tn;
+    t = f - b * Tn;
+  }
+  for (int i = threadIdx.x; i < C * W; i += blockDim.x) {
+    const int c = i / W, w = i - c * W;
+    const size_t src = chan_outer ? (((size_t)b * C + c) * Tn + t) * S + (size_t)h * W + w
+                                  : (((size_t)b * Tn + t) * C + c) * S + (size_t)h * W + w;
+    srow[i] = x[src];
+  }
+  __syncthreads();
+  const int J8 = Jp >> 3, kwc = kw * C;
+  for (int i = threadIdx.x; i < Wo * J8; i += blockDim.x) {  // one 8-channel chunk of one output pixel
+    const int wo = i / J8, ch = i - wo * J8;
+    F8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int q = ch * 8 + e;
+      float val = 0.f;
+      if (q < kwc) {
+        const int j = q / C, c = q - j * C;
+        const int w = wo * sw - pw + j;
+        if ((unsigned)w < (unsigned)W) val = srow[c * W + w];
+      }
+      v.v[e] = val;
+    }
+    store8(out + ((size_t)fh * Wo + wo) * Jp + ch * 8, v);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Max pooling over (H, W) of [N][H][W][C]; records the winning tap per output element.
 // ---------------------------------------------------------------------------
 template <typename T>
@@ -431,6 +481,22 @@ int vc_clip_to_channels_last(int dtype, const float* x, void* out, int B, int T_
              hipLaunchKernelGGL((clip_to_cl_kernel<T>), dim3(ew_grid(total)), dim3(NTHR), 0, stream, x, (T*)out, B, T_,
                                 C, S, Cp, time_major, chan_outer);)
   VC_LAUNCH_CHECK("vc_clip_to_channels_last");
+  return VC_OK;
+}
+
+int vc_clip_unfold_w(int dtype, const float* x, void* out, int B, int T_, int C, int H, int W, int kw, int sw, int pw,
+                     int Jp, int time_major, int chan_outer, hipStream_t stream) {
+  VC_CHECK_ARG(x && out, "vc_clip_unfold_w: null pointer");
+  VC_CHECK_SHAPE(B > 0 && T_ > 0 && C > 0 && H > 0 && W > 0 && kw > 0 && sw > 0 && pw >= 0 && Jp >= kw * C &&
+                     Jp % 8 == 0 && W + 2 * pw >= kw,
+                 "vc_clip_unfold_w: bad shape");
+  const int Wo = (W + 2 * pw - kw) / sw + 1;
+  const int64_t rows = (int64_t)B * T_ * H;
+  VC_CHECK_SHAPE(rows < (1ll << 31) && (size_t)C * W * sizeof(float) <= 48 * 1024, "vc_clip_unfold_w: image too large");
+  DISPATCH_T(dtype, "vc_clip_unfold_w",
+             hipLaunchKernelGGL((clip_unfold_w_kernel<T>), dim3((unsigned)rows), dim3(NTHR), (size_t)C * W * sizeof(float),
+                                stream, x, (T*)out, B, T_, C, H, W, Wo, kw, sw, pw, Jp, time_major, chan_outer);)
+  VC_LAUNCH_CHECK("vc_clip_unfold_w");
   return VC_OK;
 }
 

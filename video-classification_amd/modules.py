@@ -78,10 +78,14 @@ class EncoderCNN(_HipModule):
 
     def forward(self, x_3d):
         B, T = x_3d.shape[0], x_3d.shape[1]
-        a = ops.clip_to_frames(x_3d, self.compute_dtype)                      # [T*B,1,H,W,8]
+        a = None
         for i, k in enumerate(self.kernels):
             blk = getattr(self, f"conv{i + 1}")
-            a = ops.conv_bn(a, blk[0].weight, blk[1], T, blk[0].bias, (1, k, k), (1, 2, 2), 0, relu=True)
+            if i == 0:  # 3-channel layer: taps along W folded into the channel axis by the layout kernel
+                a = ops.input_conv(x_3d, blk[0].weight, blk[0].bias, (1, k, k), (1, 2, 2), 0, "clip",
+                                   self.compute_dtype, bn=blk[1], groups=T, relu=True)
+            else:
+                a = ops.conv_bn(a, blk[0].weight, blk[1], T, blk[0].bias, (1, k, k), (1, 2, 2), 0, relu=True)
         # flatten(NCHW) + fc1 == a convolution whose kernel covers the whole feature map
         hf, wf = self.feat_hw
         y = ops.conv(a, self.fc1.weight, self.fc1.bias, (1, hf, wf), 1, 0, relu=True, ci=a.shape[-1])
@@ -153,10 +157,10 @@ def make_resnet_trunk(arch="resnet152"):
     return trunk
 
 
-def run_resnet_trunk(trunk, a, T):
-    """a: channels-last frames [F,1,H,W,8] -> pooled features [F, 2048]."""
-    y = ops.conv(a, trunk[0].weight, None, (1, 7, 7), (1, 2, 2), (0, 3, 3))
-    a = ops.batch_norm(y, trunk[1], T, relu=True)
+def run_resnet_trunk(trunk, x_3d, T, dtype):
+    """x_3d: raw fp32 clip [B,T,3,H,W] -> pooled features [T*B, 2048] (frames time-major)."""
+    a = ops.input_conv(x_3d, trunk[0].weight, None, (1, 7, 7), (1, 2, 2), (0, 3, 3), "clip", dtype, bn=trunk[1],
+                       groups=T, relu=True)
     F_, _, H, W, C = a.shape
     a = ops.max_pool2d(a.view(F_, H, W, C), 3, 2, 1)
     a = a.view(F_, 1, a.shape[1], a.shape[2], C)
@@ -198,8 +202,7 @@ class ResCNNEncoder(_HeadBN):
 
     def forward(self, x_3d):
         B, T = x_3d.shape[0], x_3d.shape[1]
-        a = ops.clip_to_frames(x_3d, self.compute_dtype)
-        f = run_resnet_trunk(self.resnet, a, T)
+        f = run_resnet_trunk(self.resnet, x_3d, T, self.compute_dtype)
         return _frames_to_seq(self._head(f, T, False), T, B)
 
 
@@ -264,11 +267,14 @@ class Conv3DModel(_HipModule):
                                 nn.Dropout(config.dropout_p), nn.Linear(512, config.num_classes))
 
     def forward(self, x):
-        a = ops.volume_to_cl(x, self.compute_dtype)                # [B,T,H,W,8]
+        a = None
         for i in range(4):
             cv, bn = self.conv3d[4 * i], self.conv3d[4 * i + 1]
-            y = ops.conv(a, cv.weight, cv.bias, 3, 1, 1)
-            a = ops.batch_norm(y, bn, groups=1, relu=True)
+            if i == 0:  # 1-channel layer straight from the fp32 volume (W taps folded into the channel axis)
+                a = ops.input_conv(x, cv.weight, cv.bias, 3, 1, 1, "volume", self.compute_dtype, bn=bn, groups=1,
+                                   relu=True)
+            else:
+                a = ops.conv_bn(a, cv.weight, bn, 1, cv.bias, 3, 1, 1, relu=True)
             B, D, H, W, C = a.shape
             a = ops.max_pool2d(a.view(B * D, H, W, C), 2, 2, 0)     # MaxPool3d((1,2,2))
             a = a.view(B, D, H // 2, W // 2, C)

@@ -294,6 +294,114 @@ class _Conv(torch.autograd.Function):
 FUSE_BN_STATS = os.environ.get("VC_FUSE_BN_STATS", "1") != "0"
 
 
+class _InputConv(torch.autograd.Function):
+    """First convolution of a network, straight from the raw fp32 clip (1 or 3 channels).
+
+    The kw taps along W are folded into the channel axis by the layout kernel (vc_clip_unfold_w), so the layer
+    is a (kd, kh, 1) convolution over pad8(kw*C) channels instead of a (kd, kh, kw) one over C padded to 8:
+    2.3x fewer products for a 7x7 / 3-channel stem, 3x for a 3x3x3 / 1-channel one.  The clip needs no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, kernel, stride, padding, layout, dtype, stats_groups):
+        _require_cuda(x, "input_conv")
+        x = x.contiguous().float()
+        k, s, p = _triple(kernel), _triple(stride), _triple(padding)
+        if layout == "clip":      # [B,T,C,H,W] -> frames, time-major (frame = t*B + b), depth 1
+            B, T, C, H, W = x.shape
+            N, D, tm, chan_outer = T * B, 1, 1, 0
+        elif layout == "volume":  # [B,C,T,H,W] -> [B,T,H,W]
+            B, C, T, H, W = x.shape
+            N, D, tm, chan_outer = B, T, 0, 1
+        else:
+            raise ValueError(layout)
+        co, ci = weight.shape[0], weight.shape[1]
+        if ci != C or weight.numel() != co * ci * k[0] * k[1] * k[2]:
+            raise RuntimeError(f"input_conv: weight {tuple(weight.shape)} does not match {C} channels / kernel {k}")
+        code = L.dtype_code(dtype)
+        kw, sw, pw = k[2], s[2], p[2]
+        Wo = (W + 2 * pw - kw) // sw + 1
+        Jp = pad8(kw * C)
+        U = torch.empty(N, D, H, Wo, Jp, device=x.device, dtype=dtype)
+        L.call("vc_clip_unfold_w", code, L.ptr(x), L.ptr(U), B, T, C, H, W, kw, sw, pw, Jp, tm, chan_outer, L.stream())
+        to = k[0] * k[1]
+        cop = pad8(co)
+        Do = (D + 2 * p[0] - k[0]) // s[0] + 1
+        Ho = (H + 2 * p[1] - k[1]) // s[1] + 1
+        desc = [N, D, H, Wo, Jp, Do, Ho, Wo, cop, k[0], k[1], 1, s[0], s[1], 1, p[0], p[1], 0]
+        key = (weight.data_ptr(), weight._version, _weights_epoch, dtype, Jp, cop, to)
+        cache = getattr(weight, "_vc_pack_u", None)
+        if cache is not None and cache[0] == key:
+            wf = cache[1]
+        else:
+            wf = torch.empty(cop, to, Jp, device=x.device, dtype=dtype)
+            L.call("vc_pack_weight_unfold", code, L.ptr(weight.detach().contiguous()), L.ptr(wf), co, ci, to, kw, Jp,
+                   cop, L.stream())
+            weight._vc_pack_u = (key, wf)
+        b = None
+        if bias is not None:
+            b = bias.detach()
+            if cop != co:
+                b = torch.cat([b, b.new_zeros(cop - co)])
+        f32 = dtype == torch.float32
+        y = torch.empty(N, Do, Ho, Wo, cop, device=x.device, dtype=dtype)
+        M = N * Do * Ho * Wo
+        flops = 2.0 * M * co * ci * to * kw
+        nbytes = float(U.numel() * U.element_size() + wf.numel() * wf.element_size() + y.numel() * y.element_size())
+        partial = None
+        if (stats_groups and FUSE_BN_STATS and not f32 and M % stats_groups == 0 and (M // stats_groups) % 64 == 0 and
+                L.query("vc_conv_fwd_stats_supported", L.int_array(desc), code, 0, 0) == 1):
+            partial = torch.empty(M // 64, 2, cop, device=x.device, dtype=torch.float32)
+            _timed("conv_fwd", flops, lambda: L.call(
+                "vc_conv_fwd_stats", L.int_array(desc), code, L.ptr(U), 0, L.ptr(wf), L.ptr(b), L.ptr(y), 0, 0,
+                L.ptr(partial), L.stream()), nbytes)
+        else:
+            _timed("conv_fwd", flops, lambda: L.call(
+                "vc_conv_fwd", L.int_array(desc), code, L.ptr(U), 0, L.ptr(wf), L.ptr(b), L.ptr(y), 0, 0, int(f32), 0,
+                L.stream()), nbytes)
+        ctx.desc, ctx.flops, ctx.dims = desc, flops, (co, ci, to, kw, Jp, cop)
+        ctx.weight, ctx.bias = weight, bias
+        ctx.save_for_backward(U)
+        if partial is None:
+            partial = y.new_empty(0, dtype=torch.float32)
+        ctx.mark_non_differentiable(partial)
+        return y, partial
+
+    @staticmethod
+    def backward(ctx, dy, _dpartial=None):
+        (U,) = ctx.saved_tensors
+        co, ci, to, kw, Jp, cop = ctx.dims
+        dtype = U.dtype
+        code = L.dtype_code(dtype)
+        dy = cast(dy.contiguous(), dtype)
+        weight, bias = ctx.weight, ctx.bias
+        want_db = bias is not None and bias.requires_grad
+        dbp = None
+        if want_db:
+            dbp = _grad_buf(bias) if cop == co else _zero_scratch(None, "", (cop,), U.device)
+        desc = L.int_array(ctx.desc)
+        if weight.requires_grad:
+            dwp = _wgrad_scratch(weight, (cop, to, Jp))
+            _timed("conv_wgrad", ctx.flops, lambda: L.call(
+                "vc_conv_wgrad", desc, code, L.ptr(U), 0, L.ptr(dy), 0, L.ptr(dwp), L.ptr(dbp), 0, L.stream()))
+            L.call("vc_unpack_wgrad_unfold", L.ptr(dwp), L.ptr(_grad_buf(weight)), co, ci, to, kw, Jp, 3, L.stream())
+        elif want_db:
+            L.call("vc_colsum", code, L.ptr(dy), L.ptr(dbp), dy.numel() // cop, cop, cop, L.stream())
+        if want_db and cop != co:
+            _grad_buf(bias).add_(dbp[:co])
+        _ready(weight, bias)
+        return None, None, None, None, None, None, None, None, None
+
+
+def input_conv(x, weight, bias, kernel, stride, padding, layout, dtype, bn=None, groups=1, relu=False):
+    """conv (+ BatchNorm + ReLU when `bn` is given) of the raw fp32 clip: layout "clip" = [B,T,C,H,W] evaluated
+    per frame (time-major frames, 2-D kernel given as (1, kh, kw)), "volume" = [B,C,T,H,W] (3-D kernel)."""
+    training = bn is not None and (bn.training or bn.running_mean is None)
+    y, partial = _InputConv.apply(x, weight, bias, kernel, stride, padding, layout, dtype, groups if training else 0)
+    if bn is None:
+        return y
+    return batch_norm(y, bn, groups, relu=relu, partial=partial if partial.numel() else None)
+
+
 class GradJoin:
     """Gradient accumulator of an activation that has several consumers (the input of a residual block).
     Each consumer's backward adds its contribution into ONE buffer inside its own kernel (the data-gradient
