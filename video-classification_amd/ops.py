@@ -146,7 +146,8 @@ def _packed_weights(weight, ci, taps, cip, cop, dtype):
     if cache is not None and cache[0] == key:
         return cache[1], cache[2]
     co = weight.shape[0]
-    wf = torch.zeros(cop, taps, cip, device=weight.device, dtype=dtype)
+    # the pack kernel writes every element of the first co rows; only padded output rows need the zero fill
+    wf = (torch.empty if cop == co else torch.zeros)(cop, taps, cip, device=weight.device, dtype=dtype)
     wt = torch.empty(ci, taps, cop, device=weight.device, dtype=dtype)
     w = weight.detach().contiguous()
     L.call("vc_pack_weight", L.dtype_code(dtype), L.ptr(w), L.ptr(wf), L.ptr(wt), co, ci, taps, cip, cop, L.stream())
@@ -258,25 +259,40 @@ class _Conv(torch.autograd.Function):
         dbp = None
         if want_db:
             dbp = _grad_buf(bias) if cop == co else _zero_scratch(None, "", (cop,), x.device)
-        if weight.requires_grad:
-            if ctx.taps == 1 and cip == ci and cop == co:
-                # the packed layout IS the parameter's layout: accumulate straight into the gradient
-                dwp = _grad_buf(weight)
-                _timed("conv_wgrad", ctx.flops, lambda: L.call(
-                    "vc_conv_wgrad", desc, code, L.ptr(x), 0, L.ptr(dy), 0, L.ptr(dwp), L.ptr(dbp), 0, L.stream()))
-            else:
-                dwp = _wgrad_scratch(weight, (cop, ctx.taps, cip))
-                _timed("conv_wgrad", ctx.flops, lambda: L.call(
-                    "vc_conv_wgrad", desc, code, L.ptr(x), 0, L.ptr(dy), 0, L.ptr(dwp), L.ptr(dbp), 0, L.stream()))
-                L.call("vc_unpack_wgrad", L.ptr(dwp), L.ptr(_grad_buf(weight)), co, ci, ctx.taps, cip, 3, L.stream())
-        elif want_db:
-            M = dy.numel() // cop
-            L.call("vc_colsum", code, L.ptr(dy), L.ptr(dbp), M, cop, cop, L.stream())
-        if want_db and cop != co:  # padded channel count: fold the first co sums into the parameter's gradient
-            _grad_buf(bias).add_(dbp[:co])
-        _ready(weight, bias)
+        # The weight gradient and the data gradient of a layer are independent: optionally (WGRAD_STREAM) the
+        # first goes to a side stream; the main stream joins before anything can reuse the tensors they read.
+        need_dx = ctx.needs_input_grad[0]
+        side = _side_stream(x.device) if (WGRAD_STREAM and PROFILE is None and weight.requires_grad and need_dx) else None
+        main = torch.cuda.current_stream()
+        if side is not None:
+            side.wait_stream(main)
+
+        def weight_grads():
+            if weight.requires_grad:
+                if ctx.taps == 1 and cip == ci and cop == co:
+                    # the packed layout IS the parameter's layout: accumulate straight into the gradient
+                    dwp = _grad_buf(weight)
+                    _timed("conv_wgrad", ctx.flops, lambda: L.call(
+                        "vc_conv_wgrad", desc, code, L.ptr(x), 0, L.ptr(dy), 0, L.ptr(dwp), L.ptr(dbp), 0, L.stream()))
+                else:
+                    dwp = _wgrad_scratch(weight, (cop, ctx.taps, cip))
+                    _timed("conv_wgrad", ctx.flops, lambda: L.call(
+                        "vc_conv_wgrad", desc, code, L.ptr(x), 0, L.ptr(dy), 0, L.ptr(dwp), L.ptr(dbp), 0, L.stream()))
+                    L.call("vc_unpack_wgrad", L.ptr(dwp), L.ptr(_grad_buf(weight)), co, ci, ctx.taps, cip, 3,
+                           L.stream())
+            elif want_db:
+                M = dy.numel() // cop
+                L.call("vc_colsum", code, L.ptr(dy), L.ptr(dbp), M, cop, cop, L.stream())
+            if want_db and cop != co:  # padded channel count: fold the first co sums into the parameter's gradient
+                _grad_buf(bias).add_(dbp[:co])
+
+        if side is not None:
+            with torch.cuda.stream(side):
+                weight_grads()
+        else:
+            weight_grads()
         dx = None
-        if ctx.needs_input_grad[0]:
+        if need_dx:
             if cip != ci:
                 raise RuntimeError("conv: data gradient requested for a channel-padded input")
             join = ctx.join
@@ -287,7 +303,24 @@ class _Conv(torch.autograd.Function):
                 int(acc), L.stream()))
             if join is not None:
                 dx = join.arrive(dx)
+        if side is not None:
+            main.wait_stream(side)
+        _ready(weight, bias)
         return dx, None, None, None, None, None, None, None, None, None, None
+
+
+# VC_WGRAD_STREAM=1 runs a layer's weight gradient on a side stream beside its data gradient.  Measured on the
+# bench workloads it LOSES 3-6 % (both kernels are sized to fill the chip: sharing it costs L2 locality and
+# gains no idle time back), so the default keeps one stream.
+WGRAD_STREAM = os.environ.get("VC_WGRAD_STREAM", "0") == "1"
+_side_streams = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
 
 
 # VC_FUSE_BN_STATS=0 keeps BatchNorm statistics in their own pass over y (A/B measurements)
