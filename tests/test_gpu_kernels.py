@@ -27,10 +27,12 @@ def rnd(dt, *shape, seed=0):
 @pytest.mark.parametrize("dt", DTYPES, ids=IDS)
 @pytest.mark.parametrize("shape,groups", [((6, 1, 5, 7, 24), 3), ((8, 1, 1, 1, 96), 2), ((4, 3, 6, 6, 32), 1),
                                           ((6, 1, 3, 3, 2304), 2)])
-@pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False)])
-def test_batchnorm_groups(cuda, dt, shape, groups, relu, res):
+@pytest.mark.parametrize("relu,res,inplace", [(True, False, False), (True, True, False), (True, True, True),
+                                              (False, False, False)])
+def test_batchnorm_groups(cuda, dt, shape, groups, relu, res, inplace):
     """Training-mode BN over G groups of rows == the reference's per-time-step loop: G separate BN calls in
-    order, running stats updated G times."""
+    order, running stats updated G times.  `inplace`: the backward pass may overwrite the incoming gradient
+    with its ReLU-masked form (the residual's gradient), as the bottleneck blocks ask for."""
     from video_classification_amd import ops
     C = shape[-1]
     x = rnd(dt, *shape, seed=1) * 2 + 0.5
@@ -61,7 +63,7 @@ def test_batchnorm_groups(cuda, dt, shape, groups, relu, res):
     out_r.backward(dy)
     xm = x.to(cuda, dt).requires_grad_(True)
     rm = r.to(cuda, dt).requires_grad_(True) if res else None
-    out_m = ops.batch_norm(xm, bn_mine, groups, relu=relu, residual=rm)
+    out_m = ops.batch_norm(xm, bn_mine, groups, relu=relu, residual=rm, grad_inplace=inplace)
     out_m.backward(dy.to(cuda, dt))
     t = tol(dt)
     assert G.max_rel(out_m.float().cpu(), out_r.detach()) < t

@@ -18,12 +18,14 @@ constexpr int NTHR = 256;
 // per-(group, channel) sums of v1 and v2 over the rows of a group
 // MODE 0: v1 = y,  v2 = y*y                       (forward statistics)
 // MODE 1: v1 = dz, v2 = dz * xhat                 (backward reductions), dz = dout * (act > 0 if relu)
-template <typename T, int MODE>
-__global__ void bn_reduce_kernel(const T* __restrict__ y, const T* __restrict__ dout, const T* __restrict__ act,
+// WRITE_DZ (MODE 1 with `act`): dz is also written back over dout (dz_out aliases dout, so neither is
+// __restrict__): the masked gradient is then both the shortcut's gradient and the apply pass's input.
+template <typename T, int MODE, bool WRITE_DZ = false>
+__global__ void bn_reduce_kernel(const T* __restrict__ y, const T* dout, const T* __restrict__ act,
                                  const float* __restrict__ mean, const float* __restrict__ invstd,
                                  const float* __restrict__ scale, const float* __restrict__ shift,
                                  float* __restrict__ s1, float* __restrict__ s2, int C, int rpg, int rows_per_block,
-                                 int relu) {
+                                 int relu, T* dz_out = nullptr) {
   __shared__ float red[2][NTHR][8];
   const int C8 = C >> 3;
   const int lanesC = C8 < NTHR ? C8 : NTHR;
@@ -87,6 +89,7 @@ __global__ void bn_reduce_kernel(const T* __restrict__ y, const T* __restrict__ 
 #pragma unroll
               for (int i = 0; i < 8; ++i) dv[u].v[i] = fmaf(yv[u].v[i], sc[i], sh[i]) > 0.f ? dv[u].v[i] : 0.f;
             }
+            if (WRITE_DZ) store8(dz_out + off + (size_t)u * RL * C, dv[u]);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
               a1[i] += dv[u].v[i];
@@ -116,6 +119,7 @@ __global__ void bn_reduce_kernel(const T* __restrict__ y, const T* __restrict__ 
               for (int i = 0; i < 8; ++i) dv.v[i] = fmaf(yv.v[i], sc[i], sh[i]) > 0.f ? dv.v[i] : 0.f;
             }
           }
+          if (WRITE_DZ) store8(dz_out + off, dv);
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             a1[i] += dv.v[i];
@@ -535,18 +539,18 @@ inline int bn_reduce_blocks() {
   return v;
 }
 
-template <typename T, int MODE>
+template <typename T, int MODE, bool WRITE_DZ = false>
 int launch_reduce(const void* y, const void* dout, const void* act, const float* mean, const float* invstd,
                   const float* scale, const float* shift, float* s1, float* s2, int G, int rpg, int C, int relu,
-                  hipStream_t stream) {
+                  hipStream_t stream, void* dz_out = nullptr) {
   // about four blocks per CU: enough loads in flight to stream at HBM rate, few enough that the atomics
   // that combine the blocks stay cheap; at least 16 rows per thread
   const int C8 = C / 8, lanesC = C8 < NTHR ? C8 : NTHR, RL = NTHR / lanesC;
   int rows_per_block = 16 * RL;
   while (rows_per_block < rpg && (int64_t)ceil_div(rpg, rows_per_block) * G > bn_reduce_blocks()) rows_per_block *= 2;
   dim3 grid(ceil_div(rpg, rows_per_block), G);
-  hipLaunchKernelGGL((bn_reduce_kernel<T, MODE>), grid, dim3(NTHR), 0, stream, (const T*)y, (const T*)dout,
-                     (const T*)act, mean, invstd, scale, shift, s1, s2, C, rpg, rows_per_block, relu);
+  hipLaunchKernelGGL((bn_reduce_kernel<T, MODE, WRITE_DZ>), grid, dim3(NTHR), 0, stream, (const T*)y, (const T*)dout,
+                     (const T*)act, mean, invstd, scale, shift, s1, s2, C, rpg, rows_per_block, relu, (T*)dz_out);
   return VC_OK;
 }
 
@@ -640,6 +644,22 @@ int vc_bn_bwd_reduce(int dtype, const void* y, const void* dout, const void* act
   else if (dtype == VC_F32) launch_reduce<float, 1>(y, dout, act, mean, invstd, scale, shift, s1, s2, G, rpg, C, relu, stream);
   else { vc_set_error("vc_bn_bwd_reduce: unsupported dtype %d", dtype); return VC_ERR_DTYPE; }
   VC_LAUNCH_CHECK("vc_bn_bwd_reduce");
+  return VC_OK;
+}
+
+// vc_bn_bwd_reduce for an activation out = relu(bn(y) + residual): the ReLU mask comes from `act` (= out) and
+// the masked gradient dz = dout * (act > 0) is written back over dout.  dz is the residual's gradient as it
+// stands, and vc_bn_bwd_apply then runs on it with relu = 0 (no third read of act, no second gradient tensor).
+int vc_bn_bwd_reduce_mask(int dtype, const void* y, void* dout, const void* act, const float* mean,
+                          const float* invstd, float* s1, float* s2, int G, int rpg, int C, hipStream_t stream) {
+  VC_CHECK_ARG(y && dout && act && mean && invstd && s1 && s2, "vc_bn_bwd_reduce_mask: null pointer");
+  VC_CHECK_SHAPE(C % 8 == 0, "vc_bn_bwd_reduce_mask: need C %% 8 == 0 (C=%d)", C);
+  if (dtype == VC_BF16)
+    launch_reduce<bf16, 1, true>(y, dout, act, mean, invstd, nullptr, nullptr, s1, s2, G, rpg, C, 1, stream, dout);
+  else if (dtype == VC_F32)
+    launch_reduce<float, 1, true>(y, dout, act, mean, invstd, nullptr, nullptr, s1, s2, G, rpg, C, 1, stream, dout);
+  else { vc_set_error("vc_bn_bwd_reduce_mask: unsupported dtype %d", dtype); return VC_ERR_DTYPE; }
+  VC_LAUNCH_CHECK("vc_bn_bwd_reduce_mask");
   return VC_OK;
 }
 

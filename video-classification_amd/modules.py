@@ -125,9 +125,11 @@ class Bottleneck(nn.Module):
             idt = ops.conv_bn(x, self.downsample[0].weight, self.downsample[1], T, None, 1, (1, s, s), 0, join=join)
         a = ops.conv_bn(x, self.conv1.weight, self.bn1, T, relu=True, join=join)
         a = ops.conv_bn(a, self.conv2.weight, self.bn2, T, None, (1, 3, 3), (1, s, s), (0, 1, 1), relu=True)
+        # The block's output feeds the next block through a GradJoin, the average pool or a caller's own op, each of
+        # which hands back a gradient tensor nobody else holds: bn3's backward may mask it in place.
         if idt is not None:
-            return ops.conv_bn(a, self.conv3.weight, self.bn3, T, relu=True, residual=idt)
-        return ops.conv_bn(a, self.conv3.weight, self.bn3, T, relu=True, residual=x, res_join=join)
+            return ops.conv_bn(a, self.conv3.weight, self.bn3, T, relu=True, residual=idt, grad_inplace=True)
+        return ops.conv_bn(a, self.conv3.weight, self.bn3, T, relu=True, residual=x, res_join=join, grad_inplace=True)
 
 
 RESNET_LAYERS = {"resnet50": (3, 4, 6, 3), "resnet101": (3, 4, 23, 3), "resnet152": (3, 8, 36, 3)}

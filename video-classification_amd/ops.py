@@ -462,14 +462,14 @@ def conv(x, weight, bias=None, kernel=1, stride=1, padding=0, relu=False, out_f3
 
 
 def conv_bn(x, weight, bn, groups, bias=None, kernel=1, stride=1, padding=0, relu=False, residual=None, join=None,
-            res_join=None):
+            res_join=None, grad_inplace=False):
     """BatchNorm(conv(x)) (+ residual, ReLU).  In training the convolution's epilogue also writes the slab sums
     the BatchNorm statistics are taken from, where the geometry allows it (otherwise a separate pass reads y)."""
     training = bn.training or bn.running_mean is None
     y, partial = _Conv.apply(x, weight, bias, kernel, stride, padding, False, False, None, join,
                              groups if training else 0)
     return batch_norm(y, bn, groups, relu=relu, residual=residual, res_join=res_join,
-                      partial=partial if partial.numel() else None)
+                      partial=partial if partial.numel() else None, grad_inplace=grad_inplace)
 
 
 def linear(x, weight, bias=None, relu=False, out_f32=False):
@@ -485,9 +485,10 @@ def linear(x, weight, bias=None, relu=False, out_f32=False):
 class _BatchNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, gamma, beta, running_mean, running_var, groups, momentum, eps, relu, residual, training,
-                res_join, owner, partial):
+                res_join, owner, partial, grad_inplace=False):
         _require_cuda(y, "batch_norm")
         ctx.res_join = res_join
+        ctx.grad_inplace = grad_inplace
         ctx.owner = owner
         y = y.contiguous()
         C = y.shape[-1]
@@ -537,13 +538,23 @@ class _BatchNorm(torch.autograd.Function):
         code = L.dtype_code(y.dtype)
         dout = cast(dout.contiguous(), y.dtype)
         s = _zero_scratch(ctx.owner, "_vc_bsums", (2, G, C), y.device)  # cleared again by vc_bn_bwd_params
-        L.call("vc_bn_bwd_reduce", code, L.ptr(y), L.ptr(dout), L.ptr(out), L.ptr(stat[0]), L.ptr(stat[1]),
-               L.ptr(stat[2]), L.ptr(stat[3]), L.ptr(s[0]), L.ptr(s[1]), G, rpg, C, int(ctx.relu), L.stream())
         dy = torch.empty_like(y)
-        dres = torch.empty_like(y) if ctx.has_res else None
-        L.call("vc_bn_bwd_apply", code, L.ptr(y), L.ptr(dout), L.ptr(out), L.ptr(stat[0]), L.ptr(stat[1]),
-               L.ptr(stat[2]), L.ptr(stat[3]), L.ptr(s[0]), L.ptr(s[1]), L.ptr(dy), L.ptr(dres), G, rpg, C,
-               int(ctx.relu), L.stream())
+        if ctx.grad_inplace and ctx.relu and ctx.has_res and out is not None and BN_INPLACE_MASK:
+            # the caller owns dout: the reduce pass masks it in place, the masked gradient is the residual's
+            # gradient as it stands and the apply pass reads it without the activation
+            L.call("vc_bn_bwd_reduce_mask", code, L.ptr(y), L.ptr(dout), L.ptr(out), L.ptr(stat[0]), L.ptr(stat[1]),
+                   L.ptr(s[0]), L.ptr(s[1]), G, rpg, C, L.stream())
+            dres = dout
+            L.call("vc_bn_bwd_apply", code, L.ptr(y), L.ptr(dout), L.ptr(None), L.ptr(stat[0]), L.ptr(stat[1]),
+                   L.ptr(stat[2]), L.ptr(stat[3]), L.ptr(s[0]), L.ptr(s[1]), L.ptr(dy), L.ptr(None), G, rpg, C, 0,
+                   L.stream())
+        else:
+            L.call("vc_bn_bwd_reduce", code, L.ptr(y), L.ptr(dout), L.ptr(out), L.ptr(stat[0]), L.ptr(stat[1]),
+                   L.ptr(stat[2]), L.ptr(stat[3]), L.ptr(s[0]), L.ptr(s[1]), G, rpg, C, int(ctx.relu), L.stream())
+            dres = torch.empty_like(y) if ctx.has_res else None
+            L.call("vc_bn_bwd_apply", code, L.ptr(y), L.ptr(dout), L.ptr(out), L.ptr(stat[0]), L.ptr(stat[1]),
+                   L.ptr(stat[2]), L.ptr(stat[3]), L.ptr(s[0]), L.ptr(s[1]), L.ptr(dy), L.ptr(dres), G, rpg, C,
+                   int(ctx.relu), L.stream())
         join = ctx.res_join
         if join is not None and dres is not None:
             if join.buf is not None:
@@ -553,16 +564,22 @@ class _BatchNorm(torch.autograd.Function):
         db = _grad_buf(ctx.beta) if ctx.beta is not None and ctx.beta.requires_grad else None
         L.call("vc_bn_bwd_params", L.ptr(s[0]), L.ptr(s[1]), L.ptr(dg), L.ptr(db), G, C, 3, L.stream())
         _ready(ctx.gamma, ctx.beta)
-        return dy, None, None, None, None, None, None, None, None, dres, None, None, None, None
+        return dy, None, None, None, None, None, None, None, None, dres, None, None, None, None, None
 
 
-def batch_norm(y, bn, groups, relu=False, residual=None, res_join=None, partial=None):
+# VC_BN_INPLACE_MASK=0 keeps the gradient of a residual block's output untouched (A/B measurements)
+BN_INPLACE_MASK = os.environ.get("VC_BN_INPLACE_MASK", "1") != "0"
+
+
+def batch_norm(y, bn, groups, relu=False, residual=None, res_join=None, partial=None, grad_inplace=False):
     """bn: an nn.BatchNorm{1,2,3}d module holding the parameters/buffers (its own forward is not used).
-    res_join: optional GradJoin shared with the other consumers of `residual`."""
+    res_join: optional GradJoin shared with the other consumers of `residual`.
+    grad_inplace: the caller guarantees that nothing else reads the gradient of this call's output, so the
+    backward pass may overwrite it (relu(bn(y) + residual): the masked gradient replaces it in place)."""
     training = bn.training or bn.running_mean is None
     out = _BatchNorm.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, groups,
                            bn.momentum if bn.momentum is not None else 0.1, bn.eps, relu, residual, training,
-                           res_join, bn, partial)
+                           res_join, bn, partial, grad_inplace)
     if training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked += groups
     return out
