@@ -98,10 +98,14 @@ int vc_bn_apply(int dtype, const void* y, const float* scale, const float* shift
 int vc_bn_bwd_reduce(int dtype, const void* y, const void* dout, const void* act, const float* mean,
                      const float* invstd, const float* scale, const float* shift, float* s1, float* s2, int G, int rpg,
                      int C, int relu, vc_stream_t stream);
-/* the reduce for out = relu(bn(y) + residual) (torchvision Bottleneck's out += identity; relu): the mask comes from
- * act (= out) and dz = dout * (act > 0) is written back OVER dout.  dz is the shortcut's gradient as it stands and
- * the input of vc_bn_bwd_apply(relu = 0, act = NULL, dres = NULL): one pass less over the widest tensors */
-int vc_bn_bwd_reduce_mask(int dtype, const void* y, void* dout, const void* act, const float* mean,
+/* the pair for out = relu(bn(y) + residual) (torchvision Bottleneck's out += identity; relu): vc_bn_apply_mask is
+ * vc_bn_apply that also records the ReLU decisions, bits[row][C/8] (bit i of a byte = channel 8*cc + i positive);
+ * vc_bn_bwd_reduce_mask takes the mask from those bits and writes dz = dout * mask back OVER dout.  dz is the
+ * shortcut's gradient as it stands and the input of vc_bn_bwd_apply(relu = 0, act = NULL, dres = NULL): two
+ * passes less over the widest tensors than reading the activation twice and writing a second gradient */
+int vc_bn_apply_mask(int dtype, const void* y, const float* scale, const float* shift, const void* residual, void* out,
+                     uint8_t* bits, int G, int rpg, int C, int relu, vc_stream_t stream);
+int vc_bn_bwd_reduce_mask(int dtype, const void* y, void* dout, const uint8_t* bits, const float* mean,
                           const float* invstd, float* s1, float* s2, int G, int rpg, int C, vc_stream_t stream);
 int vc_bn_bwd_apply(int dtype, const void* y, const void* dout, const void* act, const float* mean,
                     const float* invstd, const float* scale, const float* shift, const float* s1, const float* s2,

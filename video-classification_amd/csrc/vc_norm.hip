@@ -18,14 +18,15 @@ constexpr int NTHR = 256;
 // per-(group, channel) sums of v1 and v2 over the rows of a group
 // MODE 0: v1 = y,  v2 = y*y                       (forward statistics)
 // MODE 1: v1 = dz, v2 = dz * xhat                 (backward reductions), dz = dout * (act > 0 if relu)
-// WRITE_DZ (MODE 1 with `act`): dz is also written back over dout (dz_out aliases dout, so neither is
-// __restrict__): the masked gradient is then both the shortcut's gradient and the apply pass's input.
+// WRITE_DZ (MODE 1): the ReLU decisions come from the bit mask `bits` ([row][C/8] bytes, bit i = channel 8*cc + i
+// was positive; written by bn_apply_kernel) and dz is also written back over dout (dz_out aliases dout, so neither
+// is __restrict__): the masked gradient is then both the shortcut's gradient and the apply pass's input.
 template <typename T, int MODE, bool WRITE_DZ = false>
 __global__ void bn_reduce_kernel(const T* __restrict__ y, const T* dout, const T* __restrict__ act,
                                  const float* __restrict__ mean, const float* __restrict__ invstd,
                                  const float* __restrict__ scale, const float* __restrict__ shift,
                                  float* __restrict__ s1, float* __restrict__ s2, int C, int rpg, int rows_per_block,
-                                 int relu, T* dz_out = nullptr) {
+                                 int relu, T* dz_out = nullptr, const uint8_t* __restrict__ bits = nullptr) {
   __shared__ float red[2][NTHR][8];
   const int C8 = C >> 3;
   const int lanesC = C8 < NTHR ? C8 : NTHR;
@@ -76,13 +77,20 @@ __global__ void bn_reduce_kernel(const T* __restrict__ y, const T* dout, const T
             yv[u] = load8(y + off + (size_t)u * RL * C);
             dv[u] = load8(dout + off + (size_t)u * RL * C);
           }
-          if (relu && act) {
+          if (WRITE_DZ) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const unsigned mb = bits[((size_t)g * rpg + r + u * RL) * C8 + cc];
+#pragma unroll
+              for (int i = 0; i < 8; ++i) av[u].v[i] = (mb >> i) & 1 ? 1.f : 0.f;
+            }
+          } else if (relu && act) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) av[u] = load8(act + off + (size_t)u * RL * C);
           }
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
-            if (relu && act) {
+            if (WRITE_DZ || (relu && act)) {
 #pragma unroll
               for (int i = 0; i < 8; ++i) dv[u].v[i] = av[u].v[i] > 0.f ? dv[u].v[i] : 0.f;
             } else if (relu) {
@@ -109,7 +117,11 @@ __global__ void bn_reduce_kernel(const T* __restrict__ y, const T* dout, const T
           }
         } else {
           F8 dv = load8(dout + off);
-          if (relu) {
+          if (WRITE_DZ) {
+            const unsigned mb = bits[((size_t)g * rpg + r) * C8 + cc];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dv.v[i] = (mb >> i) & 1 ? dv.v[i] : 0.f;
+          } else if (relu) {
             if (act) {  // the activation had a residual added: its sign is not a function of y alone
               const F8 av = load8(act + off);
 #pragma unroll
@@ -245,12 +257,21 @@ __device__ __forceinline__ RowWalk row_walk(int C8, int rpg, int rows_per_block)
   return w;
 }
 
-// out = act(y * scale[g] + shift[g] (+ residual))
+// bit i = element i is positive (the ReLU decisions of 8 channels in one byte)
+__device__ __forceinline__ uint8_t positive_bits(const F8& o) {
+  unsigned m = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) m |= (o.v[i] > 0.f ? 1u : 0u) << i;
+  return (uint8_t)m;
+}
+
+// out = act(y * scale[g] + shift[g] (+ residual)); bits (nullable): [row][C/8] ReLU decisions of out
 template <typename T>
 __global__ __launch_bounds__(NTHR) void bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ scale,
                                                         const float* __restrict__ shift,
                                                         const T* __restrict__ residual, T* __restrict__ out, int C,
-                                                        int rpg, int rows_per_block, int relu) {
+                                                        int rpg, int rows_per_block, int relu,
+                                                        uint8_t* __restrict__ bits = nullptr) {
   const int C8 = C >> 3, g = blockIdx.y;
   const RowWalk w = row_walk(C8, rpg, rows_per_block);
   for (int cc = w.cl; cc < C8; cc += w.lanesC) {
@@ -281,6 +302,7 @@ __global__ __launch_bounds__(NTHR) void bn_apply_kernel(const T* __restrict__ y,
           for (int i = 0; i < 8; ++i) o.v[i] = fmaxf(o.v[i], 0.f);
         }
         store8(out + off + u * rstride, o);
+        if (bits) bits[(off + u * rstride) >> 3] = positive_bits(o);
       }
     }
     for (; r < w.r_end; r += w.RL) {
@@ -299,6 +321,7 @@ __global__ __launch_bounds__(NTHR) void bn_apply_kernel(const T* __restrict__ y,
         for (int i = 0; i < 8; ++i) o.v[i] = fmaxf(o.v[i], 0.f);
       }
       store8(out + off, o);
+      if (bits) bits[off >> 3] = positive_bits(o);
     }
   }
 }
@@ -542,7 +565,7 @@ inline int bn_reduce_blocks() {
 template <typename T, int MODE, bool WRITE_DZ = false>
 int launch_reduce(const void* y, const void* dout, const void* act, const float* mean, const float* invstd,
                   const float* scale, const float* shift, float* s1, float* s2, int G, int rpg, int C, int relu,
-                  hipStream_t stream, void* dz_out = nullptr) {
+                  hipStream_t stream, void* dz_out = nullptr, const uint8_t* bits = nullptr) {
   // about four blocks per CU: enough loads in flight to stream at HBM rate, few enough that the atomics
   // that combine the blocks stay cheap; at least 16 rows per thread
   const int C8 = C / 8, lanesC = C8 < NTHR ? C8 : NTHR, RL = NTHR / lanesC;
@@ -550,7 +573,8 @@ int launch_reduce(const void* y, const void* dout, const void* act, const float*
   while (rows_per_block < rpg && (int64_t)ceil_div(rpg, rows_per_block) * G > bn_reduce_blocks()) rows_per_block *= 2;
   dim3 grid(ceil_div(rpg, rows_per_block), G);
   hipLaunchKernelGGL((bn_reduce_kernel<T, MODE, WRITE_DZ>), grid, dim3(NTHR), 0, stream, (const T*)y, (const T*)dout,
-                     (const T*)act, mean, invstd, scale, shift, s1, s2, C, rpg, rows_per_block, relu, (T*)dz_out);
+                     (const T*)act, mean, invstd, scale, shift, s1, s2, C, rpg, rows_per_block, relu, (T*)dz_out,
+                     bits);
   return VC_OK;
 }
 
@@ -614,8 +638,17 @@ int vc_bn_eval_params(const float* gamma, const float* beta, const float* runnin
   return VC_OK;
 }
 
+int vc_bn_apply_mask(int dtype, const void* y, const float* scale, const float* shift, const void* residual, void* out,
+                     uint8_t* bits, int G, int rpg, int C, int relu, hipStream_t stream);
+
 int vc_bn_apply(int dtype, const void* y, const float* scale, const float* shift, const void* residual, void* out,
                 int G, int rpg, int C, int relu, hipStream_t stream) {
+  return vc_bn_apply_mask(dtype, y, scale, shift, residual, out, nullptr, G, rpg, C, relu, stream);
+}
+
+// vc_bn_apply that also records the ReLU decisions: bits[row][C/8], bit i of a byte = out[row][8*cc + i] > 0
+int vc_bn_apply_mask(int dtype, const void* y, const float* scale, const float* shift, const void* residual, void* out,
+                     uint8_t* bits, int G, int rpg, int C, int relu, hipStream_t stream) {
   VC_CHECK_ARG(y && scale && shift && out, "vc_bn_apply: null pointer");
   VC_CHECK_SHAPE(C % 8 == 0, "vc_bn_apply: need C %% 8 == 0 (C=%d)", C);
   VC_CHECK_SHAPE(G > 0 && G < 65536 && rpg > 0, "vc_bn_apply: bad group count %d", G);
@@ -623,10 +656,10 @@ int vc_bn_apply(int dtype, const void* y, const float* scale, const float* shift
   const dim3 grid(ceil_div(rpg, rows), G);
   if (dtype == VC_BF16)
     hipLaunchKernelGGL((bn_apply_kernel<bf16>), grid, dim3(NTHR), 0, stream, (const bf16*)y, scale, shift,
-                       (const bf16*)residual, (bf16*)out, C, rpg, rows, relu);
+                       (const bf16*)residual, (bf16*)out, C, rpg, rows, relu, bits);
   else if (dtype == VC_F32)
     hipLaunchKernelGGL((bn_apply_kernel<float>), grid, dim3(NTHR), 0, stream, (const float*)y, scale, shift,
-                       (const float*)residual, (float*)out, C, rpg, rows, relu);
+                       (const float*)residual, (float*)out, C, rpg, rows, relu, bits);
   else { vc_set_error("vc_bn_apply: unsupported dtype %d", dtype); return VC_ERR_DTYPE; }
   VC_LAUNCH_CHECK("vc_bn_apply");
   return VC_OK;
@@ -647,17 +680,20 @@ int vc_bn_bwd_reduce(int dtype, const void* y, const void* dout, const void* act
   return VC_OK;
 }
 
-// vc_bn_bwd_reduce for an activation out = relu(bn(y) + residual): the ReLU mask comes from `act` (= out) and
-// the masked gradient dz = dout * (act > 0) is written back over dout.  dz is the residual's gradient as it
-// stands, and vc_bn_bwd_apply then runs on it with relu = 0 (no third read of act, no second gradient tensor).
-int vc_bn_bwd_reduce_mask(int dtype, const void* y, void* dout, const void* act, const float* mean,
+// vc_bn_bwd_reduce for an activation out = relu(bn(y) + residual): the ReLU mask comes from the bit mask that
+// vc_bn_apply_mask recorded and the masked gradient dz = dout * mask is written back over dout.  dz is the
+// residual's gradient as it stands, and vc_bn_bwd_apply then runs on it with relu = 0 (the activation is never
+// read again, no second gradient tensor is written).
+int vc_bn_bwd_reduce_mask(int dtype, const void* y, void* dout, const uint8_t* bits, const float* mean,
                           const float* invstd, float* s1, float* s2, int G, int rpg, int C, hipStream_t stream) {
-  VC_CHECK_ARG(y && dout && act && mean && invstd && s1 && s2, "vc_bn_bwd_reduce_mask: null pointer");
+  VC_CHECK_ARG(y && dout && bits && mean && invstd && s1 && s2, "vc_bn_bwd_reduce_mask: null pointer");
   VC_CHECK_SHAPE(C % 8 == 0, "vc_bn_bwd_reduce_mask: need C %% 8 == 0 (C=%d)", C);
   if (dtype == VC_BF16)
-    launch_reduce<bf16, 1, true>(y, dout, act, mean, invstd, nullptr, nullptr, s1, s2, G, rpg, C, 1, stream, dout);
+    launch_reduce<bf16, 1, true>(y, dout, nullptr, mean, invstd, nullptr, nullptr, s1, s2, G, rpg, C, 1, stream, dout,
+                                 bits);
   else if (dtype == VC_F32)
-    launch_reduce<float, 1, true>(y, dout, act, mean, invstd, nullptr, nullptr, s1, s2, G, rpg, C, 1, stream, dout);
+    launch_reduce<float, 1, true>(y, dout, nullptr, mean, invstd, nullptr, nullptr, s1, s2, G, rpg, C, 1, stream, dout,
+                                  bits);
   else { vc_set_error("vc_bn_bwd_reduce_mask: unsupported dtype %d", dtype); return VC_ERR_DTYPE; }
   VC_LAUNCH_CHECK("vc_bn_bwd_reduce_mask");
   return VC_OK;

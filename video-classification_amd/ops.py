@@ -520,29 +520,36 @@ class _BatchNorm(torch.autograd.Function):
                    L.ptr(stat[3]), C, float(eps), L.stream())
         out = torch.empty_like(y)
         res = residual.contiguous() if residual is not None else None
-        L.call("vc_bn_apply", code, L.ptr(y), L.ptr(stat[2]), L.ptr(stat[3]), L.ptr(res), L.ptr(out), G, rpg, C,
-               int(relu), L.stream())
+        bits = None
+        if grad_inplace and relu and res is not None and training and BN_INPLACE_MASK:
+            # one byte per 8 channels: backward takes the ReLU decisions from it instead of re-reading `out`
+            bits = torch.empty(M, C // 8, device=dev, dtype=torch.uint8)
+            L.call("vc_bn_apply_mask", code, L.ptr(y), L.ptr(stat[2]), L.ptr(stat[3]), L.ptr(res), L.ptr(out),
+                   L.ptr(bits), G, rpg, C, 1, L.stream())
+        else:
+            L.call("vc_bn_apply", code, L.ptr(y), L.ptr(stat[2]), L.ptr(stat[3]), L.ptr(res), L.ptr(out), G, rpg, C,
+                   int(relu), L.stream())
         ctx.G, ctx.rpg, ctx.C, ctx.relu, ctx.training = G, rpg, C, relu, training
         ctx.has_res = residual is not None
         ctx.gamma, ctx.beta = gamma, beta
         # the ReLU mask is recomputed from y in backward unless a residual entered in front of the ReLU
-        ctx.save_for_backward(y, out if (relu and residual is not None) else None, stat)
+        ctx.save_for_backward(y, out if (relu and residual is not None and bits is None) else None, stat, bits)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         if not ctx.training:
             raise RuntimeError("batch_norm: backward through eval-mode BatchNorm is not implemented")
-        y, out, stat = ctx.saved_tensors
+        y, out, stat, bits = ctx.saved_tensors
         G, rpg, C = ctx.G, ctx.rpg, ctx.C
         code = L.dtype_code(y.dtype)
         dout = cast(dout.contiguous(), y.dtype)
         s = _zero_scratch(ctx.owner, "_vc_bsums", (2, G, C), y.device)  # cleared again by vc_bn_bwd_params
         dy = torch.empty_like(y)
-        if ctx.grad_inplace and ctx.relu and ctx.has_res and out is not None and BN_INPLACE_MASK:
+        if bits is not None:
             # the caller owns dout: the reduce pass masks it in place, the masked gradient is the residual's
             # gradient as it stands and the apply pass reads it without the activation
-            L.call("vc_bn_bwd_reduce_mask", code, L.ptr(y), L.ptr(dout), L.ptr(out), L.ptr(stat[0]), L.ptr(stat[1]),
+            L.call("vc_bn_bwd_reduce_mask", code, L.ptr(y), L.ptr(dout), L.ptr(bits), L.ptr(stat[0]), L.ptr(stat[1]),
                    L.ptr(s[0]), L.ptr(s[1]), G, rpg, C, L.stream())
             dres = dout
             L.call("vc_bn_bwd_apply", code, L.ptr(y), L.ptr(dout), L.ptr(None), L.ptr(stat[0]), L.ptr(stat[1]),
