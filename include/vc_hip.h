@@ -57,6 +57,15 @@ int vc_conv_fwd_stats(const int* desc, int dtype, const void* x, int ldx, const 
                       void* y, int ldy, int relu, float* bn_partial, vc_stream_t stream);
 int vc_conv_dgrad(const int* desc, int dtype, const void* dy, int lddy, const void* w_packed_t, void* dx, int lddx,
                   int out_f32, int beta, vc_stream_t stream);
+/* vc_conv_dgrad (bf16, stride 1, dense rows, beta as above) for the LAST contribution to the gradient of a residual
+ * block's output out = relu(bn(y) + shortcut) (torchvision Bottleneck.forward; the block input feeds conv1 and the
+ * next shortcut): after the accumulation the epilogue multiplies dx by the ReLU decisions in tail_bits ([M][ci/8],
+ * from vc_bn_apply_mask), and writes per 64-row slab the sums of dz = dx and of dz * tail_y (tail_y = the BatchNorm's
+ * input y, same layout as dx) to bn_partial [ceil(M/64)][2][ci], every entry written.  vc_bn_bwd_sums_from_partial
+ * turns them into the BatchNorm backward reductions, so no separate pass reads dx and y for them. */
+int vc_conv_dgrad_bn_tail_supported(const int* desc, int dtype);
+int vc_conv_dgrad_bn_tail(const int* desc, int dtype, const void* dy, const void* w_packed_t, void* dx, int beta,
+                          const void* tail_y, const uint8_t* tail_bits, float* bn_partial, vc_stream_t stream);
 /* dw_packed (fp32 [co][taps][ci]) is accumulated into with atomics: the caller zeroes it.  dbias (nullable, fp32
  * [co]) receives += the column sums of dy, i.e. the bias gradient of the same layer, from the same pass over dy. */
 int vc_conv_wgrad(const int* desc, int dtype, const void* x, int ldx, const void* dy, int lddy, float* dw_packed,
@@ -107,6 +116,9 @@ int vc_bn_apply_mask(int dtype, const void* y, const float* scale, const float* 
                      uint8_t* bits, int G, int rpg, int C, int relu, vc_stream_t stream);
 int vc_bn_bwd_reduce_mask(int dtype, const void* y, void* dout, const uint8_t* bits, const float* mean,
                           const float* invstd, float* s1, float* s2, int G, int rpg, int C, vc_stream_t stream);
+/* s1[g][c] += sum dz, s2[g][c] += sum dz * xhat from the slab sums of vc_conv_dgrad_bn_tail (rpg = 64 * spg) */
+int vc_bn_bwd_sums_from_partial(const float* partial, const float* mean, const float* invstd, float* s1, float* s2,
+                                int G, int spg, int C, vc_stream_t stream);
 int vc_bn_bwd_apply(int dtype, const void* y, const void* dout, const void* act, const float* mean,
                     const float* invstd, const float* scale, const float* shift, const float* s1, const float* s2,
                     void* dy, void* dres, int G, int rpg, int C, int relu, vc_stream_t stream);

@@ -173,3 +173,52 @@ def test_conv_fwd_with_bn_slab_sums(cuda, shape):
         L.call("vc_bn_stats_from_partial", L.ptr(part), L.ptr(sums[0]), L.ptr(sums[1]), 1, slabs, cop, L.stream())
         torch.cuda.synchronize()
         assert _rel(sums[:, 0].cpu(), ref.sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("shape,beta", [((4, 8, 8, 64, 256), 1), ((3, 7, 9, 128, 512), 1), ((2, 8, 8, 64, 256), 0)],
+                         ids=["64_256_acc", "128_512_ragged_acc", "64_256_write"])
+def test_conv_dgrad_with_bn_tail(cuda, shape, beta):
+    """vc_conv_dgrad_bn_tail (the data gradient that completes the gradient of a residual block's output): the
+    stored gradient equals vc_conv_dgrad followed by the recorded ReLU decisions (bit-exact), the slab sums equal
+    sums over the stored values, and vc_bn_bwd_sums_from_partial reproduces vc_bn_bwd_reduce_mask's reductions."""
+    from video_classification_amd import _lib as L
+    N, H, W, Cmid, Cout = shape  # forward layer: 1x1 convolution Cout -> Cmid (the next block's conv1); dx has Cout channels
+    g = torch.Generator().manual_seed(11)
+    M = N * H * W
+    dy = torch.randn(M, Cmid, generator=g).to(cuda, torch.bfloat16)
+    wt = (torch.randn(Cout, 1, Cmid, generator=g) * 0.1).to(cuda, torch.bfloat16)  # data-gradient pack [ci][taps][co]
+    old = torch.randn(M, Cout, generator=g).to(cuda, torch.bfloat16)
+    y = (torch.randn(M, Cout, generator=g) * 2 + 0.3).to(cuda, torch.bfloat16)
+    bits = torch.randint(0, 256, (M, Cout // 8), generator=g, dtype=torch.uint8).to(cuda)
+    desc = L.int_array([N, 1, H, W, Cout, 1, H, W, Cmid, 1, 1, 1, 1, 1, 1, 0, 0, 0])
+    assert L.query("vc_conv_dgrad_bn_tail_supported", desc, 1) == 1
+    slabs = (M + 63) // 64
+    dx0, dx1 = old.clone(), old.clone()
+    part = torch.full((slabs, 2, Cout), float("nan"), device=cuda)
+    L.call("vc_conv_dgrad", desc, 1, L.ptr(dy), 0, L.ptr(wt), L.ptr(dx0), 0, 0, beta, L.stream())
+    L.call("vc_conv_dgrad_bn_tail", desc, 1, L.ptr(dy), L.ptr(wt), L.ptr(dx1), beta, L.ptr(y), L.ptr(bits), L.ptr(part),
+           L.stream())
+    torch.cuda.synchronize()
+    mask = ((bits.cpu().unsqueeze(-1) >> torch.arange(8, dtype=torch.uint8)) & 1).bool().view(M, Cout)
+    dz_ref = torch.where(mask, dx0.float().cpu(), torch.zeros(()))
+    assert torch.equal(dx1.float().cpu(), dz_ref)
+    pad = slabs * 64 - M
+    zp = torch.cat([dz_ref, dz_ref.new_zeros(pad, Cout)]).view(slabs, 64, Cout)
+    yp = torch.cat([y.float().cpu(), dz_ref.new_zeros(pad, Cout)]).view(slabs, 64, Cout)
+    ref = torch.stack([zp.sum(1), (zp * yp).sum(1)], 1)
+    assert not torch.isnan(part).any()
+    assert _rel(part.cpu(), ref) < 1e-5
+    if M % 64 == 0:
+        # one group: the reductions of the BatchNorm backward, from the partials and from the separate pass
+        mean = y.float().mean(0, keepdim=True).contiguous()
+        invstd = (1.0 / (y.float().var(0, unbiased=False, keepdim=True) + 1e-5).sqrt()).contiguous()
+        sa = torch.zeros(2, 1, Cout, device=cuda)
+        sb = torch.zeros(2, 1, Cout, device=cuda)
+        L.call("vc_bn_bwd_sums_from_partial", L.ptr(part), L.ptr(mean), L.ptr(invstd), L.ptr(sa[0]), L.ptr(sa[1]), 1,
+               slabs, Cout, L.stream())
+        L.call("vc_bn_bwd_reduce_mask", 1, L.ptr(y), L.ptr(dx0), L.ptr(bits), L.ptr(mean), L.ptr(invstd), L.ptr(sb[0]),
+               L.ptr(sb[1]), 1, M, Cout, L.stream())
+        torch.cuda.synchronize()
+        assert torch.equal(dx0, dx1)  # the separate pass masked its copy in place
+        assert _rel(sa[0].cpu(), sb[0].cpu()) < 1e-5
+        assert _rel(sa[1].cpu(), sb[1].cpu()) < 1e-4

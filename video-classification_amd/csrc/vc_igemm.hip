@@ -479,11 +479,19 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_fast_kernel(ConvGeom g, cons
 // LDS image and writes it out row-major, 16 bytes per lane, so that every store instruction covers whole
 // 128-byte row segments (the accumulator layout alone gives 32-byte pieces of 16 different rows).
 // `stage_buf` is this wave's private 8 KB region; the caller has made sure nobody still reads it.
-template <int MODE, int WI>
+//
+// TAIL: the output is the gradient of a residual block's output out = relu(bn(y) + shortcut), complete once this
+// tile has been added (beta) or written.  The epilogue then also applies that block's recorded ReLU decisions
+// (tail_bits [row][Co/8], one byte per 8 channels), stores the masked gradient dz, and writes the slab sums the
+// BatchNorm backward needs, bn_partial[slab][0][c] = sum dz, [slab][1][c] = sum dz * y (y = tail_y, the
+// BatchNorm's input, same [row][Co] layout as the output; requires ldc == Co, Co % 8 == 0).
+template <int MODE, int WI, bool TAIL = false>
 __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[WI][4], int m0, int n0, int wm,
                                                 int wn, int lane, const float* __restrict__ bias,
                                                 bf16* __restrict__ out, int relu, int beta, bf16* stage_buf,
-                                                float* __restrict__ bn_partial) {
+                                                float* __restrict__ bn_partial,
+                                                const bf16* __restrict__ tail_y = nullptr,
+                                                const uint8_t* __restrict__ tail_bits = nullptr) {
   constexpr int WC = WI * 16;   // channels per wave (64 or 32)
   constexpr int NCH = WC / 8;   // 16-byte chunks per image row (8 or 4)
   const int l15 = lane & 15, q = lane >> 4;
@@ -523,6 +531,8 @@ __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[
   // beta: fetch everything the tile accumulates into up front (one memory latency, not one per row group)
   bf16x8 oldv[NIT];
   bf16* orow[NIT];
+  bf16x8 tyv[TAIL ? NIT : 1];
+  unsigned tbits[TAIL ? NIT : 1];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int m = m0 + wm * 64 + it * RPI + rr;
@@ -530,13 +540,21 @@ __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[
     orow[it] = live ? out + (size_t)(MODE == 2 ? phase_out_pixel(g, m) : m) * g.ldc + co : nullptr;
     oldv[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
     if (beta && live && vec) oldv[it] = *reinterpret_cast<const bf16x8*>(orow[it]);
+    if (TAIL) {
+      tyv[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      tbits[it] = 0;
+      if (live) {
+        tyv[it] = *reinterpret_cast<const bf16x8*>(tail_y + (size_t)m * g.Co + co);
+        tbits[it] = tail_bits[((size_t)m * g.Co + co) >> 3];
+      }
+    }
   }
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int row = it * RPI + rr;
     const int m = m0 + wm * 64 + row;
     bf16x8 v = *reinterpret_cast<const bf16x8*>(stage_buf + row * WC + ((ch ^ (row & (NCH - 1))) << 3));
-    if (bn_partial && m < g.M) {
+    if (!TAIL && bn_partial && m < g.M) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float t = (float)v[e];
@@ -545,7 +563,18 @@ __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[
       }
     }
     bf16* op = orow[it];
-    if (op) {
+    if (TAIL) {  // host guarantees vec; rows beyond M carry zero bits and contribute nothing
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = (float)v[e];
+        if (beta) t += (float)oldv[it][e];
+        v[e] = ((tbits[it] >> e) & 1) ? (bf16)t : (bf16)0.f;
+        const float dz = (float)v[e];
+        ps[e] += dz;
+        pq[e] = fmaf(dz, (float)tyv[it][e], pq[e]);
+      }
+      if (op) *reinterpret_cast<bf16x8*>(op) = v;
+    } else if (op) {
       if (vec) {
         if (beta) {
 #pragma unroll
@@ -598,13 +627,15 @@ __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[
 // pipeline runs straight through the tile boundaries, so the first k-tile of the next output tile is already
 // streaming in while the epilogue of the current one is written.  Layers with a short reduction (1x1
 // convolutions with 64..256 channels are 1..4 k-tiles deep) otherwise pay a full memory latency per block.
-template <int MODE, int TN_>
+template <int MODE, int TN_, bool TAIL = false>
 __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, const bf16* __restrict__ src,
                                                                    const bf16* __restrict__ wgt,
                                                                    const float* __restrict__ bias,
                                                                    void* __restrict__ out, int relu, int out_f32,
                                                                    int beta, int ntiles,
-                                                                   float* __restrict__ bn_partial) {
+                                                                   float* __restrict__ bn_partial,
+                                                                   const bf16* __restrict__ tail_y = nullptr,
+                                                                   const uint8_t* __restrict__ tail_bits = nullptr) {
   __shared__ __attribute__((aligned(1024))) bf16 smem[2 * (BM + TN_) * BK];
   constexpr int WI = TN_ / 32;   // 16-channel tiles per wave
   constexpr int NWROW = TN_ / 32;  // weight rows staged per thread
@@ -733,9 +764,9 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
       } else {
         // the buffer that was just multiplied is free once every wave has finished reading it
         __syncthreads();
-        nt_epilogue_lds<MODE, WI>(g, acc, tile_m * BM, tile_n * TN_, wm, wn, lane, bias,
-                                  reinterpret_cast<bf16*>(out), relu, beta, cbuf + wave * (64 * WI * 16),
-                                  bn_partial);
+        nt_epilogue_lds<MODE, WI, TAIL>(g, acc, tile_m * BM, tile_n * TN_, wm, wn, lane, bias,
+                                        reinterpret_cast<bf16*>(out), relu, beta, cbuf + wave * (64 * WI * 16),
+                                        bn_partial, tail_y, tail_bits);
       }
 #pragma unroll
       for (int i = 0; i < WI; ++i)
@@ -1439,6 +1470,12 @@ int launch_nt(const ConvGeom& g, int dtype, const void* src, const void* wgt, co
   return VC_OK;
 }
 
+// stride-1 data gradient whose epilogue also finishes the gradient of a residual block's output (see TAIL)
+bool dgrad_tail_eligible(const ConvGeom& g, int dtype) {
+  return nt_persist_eligible(g, dtype) && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.Co % 8 == 0 && g.ldc == g.Co &&
+         g.Co > nt_narrow();
+}
+
 }  // namespace
 
 extern "C" {
@@ -1516,6 +1553,34 @@ int vc_conv_dgrad(const int* desc, int dtype, const void* dy, int lddy, const vo
     return VC_OK;
   }
   return launch_nt<1>(g, dtype, dy, w_packed_t, nullptr, dx, 0, out_f32, beta, stream, "vc_conv_dgrad");
+}
+
+int vc_conv_dgrad_bn_tail_supported(const int* desc, int dtype) {
+  ConvGeom g;
+  if (fill_geom(g, desc, 1, "vc_conv_dgrad_bn_tail_supported")) return 0;
+  return dgrad_tail_eligible(g, dtype) ? 1 : 0;
+}
+
+// vc_conv_dgrad (bf16, stride 1, dense rows) for the LAST contribution to the gradient of a residual block's
+// output out = relu(bn(y) + shortcut): dx (+)= the data gradient, then dx *= the ReLU decisions in bits
+// ([M][ci/8], from vc_bn_apply_mask), and bn_partial [ceil(M/64)][2][ci] receives per 64-row slab the sums of
+// dz = dx and of dz * y (every entry written), from which vc_bn_bwd_sums_from_partial forms the BatchNorm
+// backward reductions without a pass over dx and y.
+int vc_conv_dgrad_bn_tail(const int* desc, int dtype, const void* dy, const void* w_packed_t, void* dx, int beta,
+                          const void* tail_y, const uint8_t* tail_bits, float* bn_partial, hipStream_t stream) {
+  ConvGeom g;
+  int rc = fill_geom(g, desc, 1, "vc_conv_dgrad_bn_tail");
+  if (rc) return rc;
+  VC_CHECK_ARG(dy && w_packed_t && dx && tail_y && tail_bits && bn_partial, "vc_conv_dgrad_bn_tail: null pointer");
+  VC_CHECK_SHAPE(dgrad_tail_eligible(g, dtype),
+                 "vc_conv_dgrad_bn_tail: unsupported geometry (ask vc_conv_dgrad_bn_tail_supported)");
+  const int tiles = ceil_div(g.M, BM) * ceil_div(g.Co, BN);
+  const int grid = tiles < nt_persist_blocks() ? tiles : nt_persist_blocks();
+  hipLaunchKernelGGL((igemm_nt_persist_kernel<1, 128, true>), dim3(grid), dim3(NTHR), 0, stream, g, (const bf16*)dy,
+                     (const bf16*)w_packed_t, (const float*)nullptr, dx, 0, 0, beta, tiles, bn_partial,
+                     (const bf16*)tail_y, tail_bits);
+  VC_LAUNCH_CHECK("vc_conv_dgrad_bn_tail");
+  return VC_OK;
 }
 
 extern "C" int vc_colsum(int dtype, const void* a, float* out, int M, int C, int lda, hipStream_t stream);

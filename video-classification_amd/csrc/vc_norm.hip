@@ -172,8 +172,12 @@ __global__ void bn_reduce_kernel(const T* __restrict__ y, const T* dout, const T
 // flags: bit 0 = update the running statistics, bit 1 = zero sum/sumsq after reading them
 // sums[g][c] += sum over the slabs of group g of partial[slab][0][c] (and [1] into sumsq); a block covers
 // `chunk` slabs of one group and 256 channels
+// mean / invstd (nullable, [G][C]): the second statistic is sum v*y and is converted to sum v*xhat on the way,
+// invstd * (sum v*y - mean * sum v) (linear, so it can be done per chunk of slabs)
 __global__ void bn_partial_reduce_kernel(const float* __restrict__ partial, float* __restrict__ sum,
-                                         float* __restrict__ sumsq, int spg, int C, int chunk) {
+                                         float* __restrict__ sumsq, int spg, int C, int chunk,
+                                         const float* __restrict__ mean = nullptr,
+                                         const float* __restrict__ invstd = nullptr) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   const int g = blockIdx.z;
   if (c >= C) return;
@@ -184,6 +188,7 @@ __global__ void bn_partial_reduce_kernel(const float* __restrict__ partial, floa
     a += p[c];
     b += p[C + c];
   }
+  if (mean) b = invstd[g * C + c] * (b - mean[g * C + c] * a);
   atomicAdd(sum + g * C + c, a);
   atomicAdd(sumsq + g * C + c, b);
 }
@@ -613,8 +618,24 @@ int vc_bn_stats_from_partial(const float* partial, float* sum, float* sumsq, int
   int chunk = 16;
   while (ceil_div(spg, chunk) * G * ceil_div(C, 256) > 2048) chunk *= 2;
   const dim3 grid(ceil_div(C, 256), ceil_div(spg, chunk), G);
-  hipLaunchKernelGGL(bn_partial_reduce_kernel, grid, dim3(256), 0, stream, partial, sum, sumsq, spg, C, chunk);
+  hipLaunchKernelGGL(bn_partial_reduce_kernel, grid, dim3(256), 0, stream, partial, sum, sumsq, spg, C, chunk,
+                     (const float*)nullptr, (const float*)nullptr);
   VC_LAUNCH_CHECK("vc_bn_stats_from_partial");
+  return VC_OK;
+}
+
+// BatchNorm backward reductions from the slab sums of vc_conv_dgrad_bn_tail (partial[slab][0][c] = sum dz,
+// [slab][1][c] = sum dz*y over 64 rows): s1[g][c] += sum dz, s2[g][c] += sum dz * xhat.  s1/s2 zeroed by the caller.
+int vc_bn_bwd_sums_from_partial(const float* partial, const float* mean, const float* invstd, float* s1, float* s2,
+                                int G, int spg, int C, hipStream_t stream) {
+  VC_CHECK_ARG(partial && mean && invstd && s1 && s2, "vc_bn_bwd_sums_from_partial: null pointer");
+  VC_CHECK_SHAPE(G > 0 && G < 65536 && spg > 0 && C > 0, "vc_bn_bwd_sums_from_partial: bad shape");
+  int chunk = 16;
+  while (ceil_div(spg, chunk) * G * ceil_div(C, 256) > 2048) chunk *= 2;
+  const dim3 grid(ceil_div(C, 256), ceil_div(spg, chunk), G);
+  hipLaunchKernelGGL(bn_partial_reduce_kernel, grid, dim3(256), 0, stream, partial, s1, s2, spg, C, chunk, mean,
+                     invstd);
+  VC_LAUNCH_CHECK("vc_bn_bwd_sums_from_partial");
   return VC_OK;
 }
 

@@ -117,7 +117,7 @@ class Bottleneck(nn.Module):
     def run(self, x, T):
         s = self.stride
         # x feeds conv1 and the shortcut: both backward paths add into one gradient buffer (no add pass)
-        join = ops.GradJoin(2) if (x.requires_grad and torch.is_grad_enabled()) else None
+        join = ops.GradJoin(2, getattr(x, "_vc_bn_tail", None)) if (x.requires_grad and torch.is_grad_enabled()) else None
         idt = None
         if self.downsample is not None:
             # evaluated before conv1 so that its backward runs after conv1's: the strided 1x1 data gradient then

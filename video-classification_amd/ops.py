@@ -298,9 +298,21 @@ class _Conv(torch.autograd.Function):
             join = ctx.join
             acc = join is not None and join.buf is not None
             dx = join.buf if acc else torch.empty_like(x)
-            _timed("conv_dgrad", ctx.flops, lambda: L.call(
-                "vc_conv_dgrad", desc, code, L.ptr(dy), 0, L.ptr(wt), L.ptr(dx), 0, int(dtype == torch.float32),
-                int(acc), L.stream()))
+            tail = join.tail if (join is not None and join.pending == 1 and FUSE_BN_TAIL) else None
+            if (tail is not None and tail.bits is not None and tuple(tail.y.shape) == tuple(dx.shape) and
+                    L.query("vc_conv_dgrad_bn_tail_supported", desc, code) == 1):
+                # x is the output of a residual block and this is the last contribution to its gradient: the
+                # epilogue applies that block's ReLU decisions and writes the slab sums its BatchNorm backward needs
+                M = dx.numel() // dx.shape[-1]
+                partial = torch.empty((M + 63) // 64, 2, dx.shape[-1], device=dx.device, dtype=torch.float32)
+                _timed("conv_dgrad", ctx.flops, lambda: L.call(
+                    "vc_conv_dgrad_bn_tail", desc, code, L.ptr(dy), L.ptr(wt), L.ptr(dx), int(acc), L.ptr(tail.y),
+                    L.ptr(tail.bits), L.ptr(partial), L.stream()))
+                tail.partial = partial
+            else:
+                _timed("conv_dgrad", ctx.flops, lambda: L.call(
+                    "vc_conv_dgrad", desc, code, L.ptr(dy), 0, L.ptr(wt), L.ptr(dx), 0, int(dtype == torch.float32),
+                    int(acc), L.stream()))
             if join is not None:
                 dx = join.arrive(dx)
         if side is not None:
@@ -435,15 +447,29 @@ def input_conv(x, weight, bias, kernel, stride, padding, layout, dtype, bn=None,
     return batch_norm(y, bn, groups, relu=relu, partial=partial if partial.numel() else None)
 
 
+class BNTail:
+    """What the producer of the LAST gradient contribution needs in order to finish the backward reductions of
+    out = relu(bn(y) + shortcut) in its own epilogue: y, the recorded ReLU decisions, and (set by that producer)
+    the slab sums it wrote.  Travels as the attribute ``_vc_bn_tail`` of `out`."""
+
+    def __init__(self):
+        self.y = self.bits = self.partial = None
+
+
+# VC_FUSE_BN_TAIL=0 keeps the BatchNorm backward reductions of residual blocks in their own pass (A/B measurements)
+FUSE_BN_TAIL = os.environ.get("VC_FUSE_BN_TAIL", "1") != "0"
+
+
 class GradJoin:
     """Gradient accumulator of an activation that has several consumers (the input of a residual block).
     Each consumer's backward adds its contribution into ONE buffer inside its own kernel (the data-gradient
     GEMM accumulates in its epilogue) and only the last consumer to arrive hands the buffer to autograd, so
     no separate elementwise add pass runs over the activation."""
 
-    def __init__(self, consumers):
+    def __init__(self, consumers, tail=None):
         self.pending = consumers
         self.buf = None
+        self.tail = tail  # BNTail of the residual block whose output this activation is (or None)
 
     def arrive(self, buf):
         self.buf = buf
@@ -485,10 +511,11 @@ def linear(x, weight, bias=None, relu=False, out_f32=False):
 class _BatchNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, gamma, beta, running_mean, running_var, groups, momentum, eps, relu, residual, training,
-                res_join, owner, partial, grad_inplace=False):
+                res_join, owner, partial, grad_inplace=False, tail=None):
         _require_cuda(y, "batch_norm")
         ctx.res_join = res_join
         ctx.grad_inplace = grad_inplace
+        ctx.tail = tail
         ctx.owner = owner
         y = y.contiguous()
         C = y.shape[-1]
@@ -526,6 +553,8 @@ class _BatchNorm(torch.autograd.Function):
             bits = torch.empty(M, C // 8, device=dev, dtype=torch.uint8)
             L.call("vc_bn_apply_mask", code, L.ptr(y), L.ptr(stat[2]), L.ptr(stat[3]), L.ptr(res), L.ptr(out),
                    L.ptr(bits), G, rpg, C, 1, L.stream())
+            if tail is not None and rpg % 64 == 0 and y.dtype == torch.bfloat16:
+                tail.y, tail.bits = y, bits
         else:
             L.call("vc_bn_apply", code, L.ptr(y), L.ptr(stat[2]), L.ptr(stat[3]), L.ptr(res), L.ptr(out), G, rpg, C,
                    int(relu), L.stream())
@@ -549,8 +578,15 @@ class _BatchNorm(torch.autograd.Function):
         if bits is not None:
             # the caller owns dout: the reduce pass masks it in place, the masked gradient is the residual's
             # gradient as it stands and the apply pass reads it without the activation
-            L.call("vc_bn_bwd_reduce_mask", code, L.ptr(y), L.ptr(dout), L.ptr(bits), L.ptr(stat[0]), L.ptr(stat[1]),
-                   L.ptr(s[0]), L.ptr(s[1]), G, rpg, C, L.stream())
+            tail = ctx.tail
+            if tail is not None and tail.partial is not None:
+                # the kernel that completed dout has already masked it and left slab sums of dz and dz*y
+                L.call("vc_bn_bwd_sums_from_partial", L.ptr(tail.partial), L.ptr(stat[0]), L.ptr(stat[1]), L.ptr(s[0]),
+                       L.ptr(s[1]), G, rpg // 64, C, L.stream())
+                tail.partial = None
+            else:
+                L.call("vc_bn_bwd_reduce_mask", code, L.ptr(y), L.ptr(dout), L.ptr(bits), L.ptr(stat[0]),
+                       L.ptr(stat[1]), L.ptr(s[0]), L.ptr(s[1]), G, rpg, C, L.stream())
             dres = dout
             L.call("vc_bn_bwd_apply", code, L.ptr(y), L.ptr(dout), L.ptr(None), L.ptr(stat[0]), L.ptr(stat[1]),
                    L.ptr(stat[2]), L.ptr(stat[3]), L.ptr(s[0]), L.ptr(s[1]), L.ptr(dy), L.ptr(None), G, rpg, C, 0,
@@ -571,7 +607,7 @@ class _BatchNorm(torch.autograd.Function):
         db = _grad_buf(ctx.beta) if ctx.beta is not None and ctx.beta.requires_grad else None
         L.call("vc_bn_bwd_params", L.ptr(s[0]), L.ptr(s[1]), L.ptr(dg), L.ptr(db), G, C, 3, L.stream())
         _ready(ctx.gamma, ctx.beta)
-        return dy, None, None, None, None, None, None, None, None, dres, None, None, None, None, None
+        return dy, None, None, None, None, None, None, None, None, dres, None, None, None, None, None, None
 
 
 # VC_BN_INPLACE_MASK=0 keeps the gradient of a residual block's output untouched (A/B measurements)
@@ -584,9 +620,12 @@ def batch_norm(y, bn, groups, relu=False, residual=None, res_join=None, partial=
     grad_inplace: the caller guarantees that nothing else reads the gradient of this call's output, so the
     backward pass may overwrite it (relu(bn(y) + residual): the masked gradient replaces it in place)."""
     training = bn.training or bn.running_mean is None
+    tail = BNTail() if (grad_inplace and relu and residual is not None and training and torch.is_grad_enabled()) else None
     out = _BatchNorm.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, groups,
                            bn.momentum if bn.momentum is not None else 0.1, bn.eps, relu, residual, training,
-                           res_join, bn, partial, grad_inplace)
+                           res_join, bn, partial, grad_inplace, tail)
+    if tail is not None and tail.bits is not None:
+        out._vc_bn_tail = tail
     if training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked += groups
     return out
