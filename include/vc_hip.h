@@ -194,6 +194,16 @@ int vc_lstm_persist_supported(int dtype, int B, int H, int ndir);
 int vc_lstm_persist_fwd(int dtype, const float* const* gates_x, const void* const* w_hh, void* const* hs, int ldh,
                         float* const* act, float* const* c, void* const* xchg, int* err, int T, int B, int H,
                         int ndir, vc_stream_t stream);
+/* Backward recurrence (BPTT) of the same layer in one persistent launch: per direction dh_out (bf16, gradient of the
+ * layer output at dh_out[(t*B + b)*ldo + j]), act / c as saved by the forward pass, w_hh_t = W_hh^T [H][4H] bf16 held in
+ * registers, dgates [T][B][4H] bf16 receives the gate pre-activation gradients of every step (what the sequence-wide
+ * weight- and input-gradient GEMMs read); xchg = scratch of vc_lstm_persist_bwd_xchg_bytes(B, H) bytes (zeroed by the
+ * call).  Supported for H a power of two in 32..512 (vc_lstm_persist_bwd_supported). */
+long long vc_lstm_persist_bwd_xchg_bytes(int B, int H);
+int vc_lstm_persist_bwd_supported(int dtype, int B, int H, int ndir);
+int vc_lstm_persist_bwd(int dtype, const void* const* dh_out, int ldo, const float* const* act, const float* const* c,
+                        const void* const* w_hh_t, void* const* dgates, void* const* xchg, int* err, int T, int B,
+                        int H, int ndir, vc_stream_t stream);
 /* ---- LSTM cell (gate order i,f,g,o; nn.LSTM at model_components.py:209-214, 482-483) -------------- */
 int vc_lstm_cell_fwd(int dtype, const float* gates_x, int ldx, const float* gates_h, const float* c_prev, void* h_out,
                      int ldh, float* c_out, float* act_out, int B, int H, vc_stream_t stream);

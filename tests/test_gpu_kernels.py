@@ -227,9 +227,10 @@ def test_layernorm(cuda, dt, M, C):
                                                    (4, 8, 96, 256, 2, True), (5, 3, 24, 32, 1, False),
                                                    (7, 40, 64, 64, 1, True)])
 def test_persistent_lstm_matches_stepwise(cuda, T, B, In, H, layers, bidir):
-    """The persistent LSTM kernel (W_hh in registers, h exchanged in tagged granules) against the per-step
-    GEMM + cell kernels on the same bf16 inputs: same math, different accumulation order -> 2e-2 of the
-    output scale (bf16 h feeds back T times), and the saved c within 2e-2 as well."""
+    """The persistent LSTM kernels (W_hh / W_hh^T in registers, h and the gate gradients exchanged in tagged
+    granules) against the per-step GEMM + cell kernels on the same bf16 inputs, forward alone and forward +
+    backward: same math, different accumulation order -> 2e-2 of the output scale (bf16 h feeds back T times),
+    5e-2 of the gradient scale (input gradient, W_hh and W_ih gradients of the first layer)."""
     from video_classification_amd import ops
     g = torch.Generator().manual_seed(T * 1000 + H)
     dirs = 2 if bidir else 1
@@ -245,19 +246,29 @@ def test_persistent_lstm_matches_stepwise(cuda, T, B, In, H, layers, bidir):
     x = torch.randn(T, B, In, generator=g).to(cuda, torch.bfloat16)
     from video_classification_amd import _lib as L
     assert L.query("vc_lstm_persist_supported", 1, B, H, dirs) == 1
+    assert L.query("vc_lstm_persist_bwd_supported", 1, B, H, dirs) == 1
     outs = []
-    for flag in (False, True):
-        ops.PERSISTENT_LSTM = flag
-        for p in params:
-            p.grad = None
-        xx = x.clone().requires_grad_(True)
-        y = ops._LSTM.apply(xx, H, layers, bidir, 0.0, *params)
-        y.float().pow(2).sum().backward()
-        torch.cuda.synchronize()
-        outs.append((y.detach().float().cpu(), xx.grad.float().cpu(), params[1].grad.clone().cpu()))
-    ops.PERSISTENT_LSTM = True
+    try:
+        for fwd, bwd in ((False, False), (True, False), (True, True)):
+            ops.PERSISTENT_LSTM, ops.PERSISTENT_LSTM_BWD = fwd, bwd
+            for p in params:
+                p.grad = None
+            xx = x.clone().requires_grad_(True)
+            y = ops._LSTM.apply(xx, H, layers, bidir, 0.0, *params)
+            # a loss that weights time steps and features unevenly (the decoders read the last step only)
+            wgt = torch.linspace(0.2, 1.0, T, device=cuda).view(T, 1, 1)
+            (y.float().pow(2) * wgt).sum().backward()
+            torch.cuda.synchronize()
+            outs.append((y.detach().float().cpu(), xx.grad.float().cpu(), params[1].grad.clone().cpu(),
+                         params[0].grad.clone().cpu()))
+    finally:
+        ops.PERSISTENT_LSTM = ops.PERSISTENT_LSTM_BWD = True
     ops.check_lstm_error()
     scale = outs[0][0].abs().max().item()
-    assert (outs[0][0] - outs[1][0]).abs().max().item() < 2e-2 * scale
-    assert (outs[0][1] - outs[1][1]).abs().max().item() < 5e-2 * outs[0][1].abs().max().item()
-    assert (outs[0][2] - outs[1][2]).abs().max().item() < 5e-2 * outs[0][2].abs().max().item()
+    for o in outs[1:]:
+        assert (outs[0][0] - o[0]).abs().max().item() < 2e-2 * scale
+        for i in (1, 2, 3):
+            assert (outs[0][i] - o[i]).abs().max().item() < 5e-2 * outs[0][i].abs().max().item(), i
+    # same forward, backward recurrence per step vs persistent: only the summation order of dh differs
+    for i in (1, 2, 3):
+        assert (outs[1][i] - outs[2][i]).abs().max().item() < 2e-2 * outs[1][i].abs().max().item(), i

@@ -219,57 +219,71 @@ def test_resnet_crnn_vs_oracle(cuda, dt):
 
 
 def test_resnet_identity_blocks_fused_bn_backward(cuda):
-    """Identity-shortcut bottleneck blocks (trunk [2,2,1,1]) in bf16: the data-gradient GEMM that completes the
-    gradient of a block's output also applies that block's ReLU decisions and leaves the slab sums of its BatchNorm
-    backward (vc_conv_dgrad_bn_tail).  The trunk alone (frames in, pooled features out, random feature gradient)
-    is run with the fusion on and off: identical features, and gradients that differ only by the order in which
-    the reductions are summed.  The features are also held against the CPU oracle's trunk.
+    """Two bottleneck blocks in a row (a projection-shortcut block, then an identity-shortcut block; the pair that
+    opens every ResNet stage) in bf16, 2 time steps x 6 frames of 16 x 16 x 64: the data-gradient GEMM of the second
+    block's conv1 completes the gradient of the first block's output, applies that block's ReLU decisions and
+    leaves the slab sums of its bn3 backward (vc_conv_dgrad_bn_tail).  One forward pass is walked backward twice,
+    fusion on and off: gradients equal up to the summation order of the reductions.  Output and gradients are
+    also checked against the CPU oracle's blocks run per time step (bf16 bounds of this file's header).
 
-    The gradients are NOT compared with the oracle here: for a randomly initialised residual trunk with batch
-    statistics over a few frames the problem itself is ill-conditioned -- the oracle's own fp32 and fp64 gradients
-    differ by 6e-3, and merely rounding the input clip to bf16 moves the oracle's gradients by 13-31 % (measured
-    with this trunk).  Gradient parity with the oracle is held at well-conditioned sizes by the tests above."""
+    A pair of blocks rather than a whole trunk: through a whole randomly initialised trunk with batch statistics
+    over a few frames the gradient is too ill-conditioned to test -- the oracle's own fp32 and fp64 gradients
+    differ by 6e-3 there, rounding the input clip to bf16 moves them by 13-31 %, and two bf16 runs whose
+    BatchNorm sums were added in a different order differ by up to 6 % (measured on a [2,2,1,1] trunk, 64 x 64)."""
     from oracle import torch_oracle as O
     from video_classification_amd import modules as M
     from video_classification_amd import ops
-    O.RESNET_LAYERS["tiny2"] = (2, 2, 1, 1)
-    M.RESNET_LAYERS["tiny2"] = (2, 2, 1, 1)
-    torch.manual_seed(4)
-    ref = O.make_resnet_trunk("tiny2")
-    B, T = 6, 2
-    x = torch.randn(B, T, 3, 64, 64, generator=torch.Generator().manual_seed(6))
-    dy = torch.randn(T * B, 2048, generator=torch.Generator().manual_seed(8)).bfloat16().float()
+    torch.manual_seed(9)
+    ds = nn.Sequential(nn.Conv2d(64, 256, 1, bias=False), nn.BatchNorm2d(256))
+    ref = nn.Sequential(O.Bottleneck(64, 64, 1, ds), O.Bottleneck(256, 64))
+    for m in ref.modules():
+        if isinstance(m, nn.BatchNorm2d):  # non-trivial affine parameters
+            nn.init.uniform_(m.weight, 0.5, 1.5)
+            nn.init.uniform_(m.bias, -0.3, 0.3)
+    mine = nn.Sequential(M.Bottleneck(64, 64, 1, nn.Sequential(nn.Conv2d(64, 256, 1, bias=False), nn.BatchNorm2d(256))),
+                         M.Bottleneck(256, 64))
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    mine.to(cuda).train()
+    B, T, S = 6, 2, 16
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(T * B, 64, S, S, generator=g).bfloat16().float()           # frames time-major, NCHW
+    dy = torch.randn(T * B, 256, S, S, generator=g).bfloat16().float()
     ref.train()
-    with torch.no_grad():
-        feats = torch.cat([ref(x[:, t]).flatten(1) for t in range(T)])  # time-major rows, as the HIP trunk returns them
-    runs = {}
-    for fused in (True, False):
-        ops.FUSE_BN_TAIL = fused
-        orig = ops.L.call
-        fused_calls = []
-        ops.L.call = lambda name, *a: (fused_calls.append(name) if name == "vc_conv_dgrad_bn_tail" else None,
-                                       orig(name, *a))[1]
-        try:
-            mine = M.make_resnet_trunk("tiny2")
-            mine.load_state_dict(ref.state_dict(), strict=True)
-            mine.to(cuda).train()
-            f = M.run_resnet_trunk(mine, x.to(cuda), T, torch.bfloat16)
-            f.backward(dy.to(cuda, torch.bfloat16))
+    xr = x.clone().requires_grad_(True)
+    out_r = torch.cat([ref(xr[t * B:(t + 1) * B]) for t in range(T)])
+    out_r.backward(dy)
+    grefs = {k: p.grad for k, p in ref.named_parameters()}
+    xm = x.permute(0, 2, 3, 1).contiguous().view(T * B, 1, S, S, 64).to(cuda, torch.bfloat16).requires_grad_(True)
+    out_m = mine[1].run(mine[0].run(xm, T), T)
+    dym = dy.permute(0, 2, 3, 1).contiguous().view(T * B, 1, S, S, 256).to(cuda, torch.bfloat16)
+    grads = {}
+    orig = ops.L.call
+    try:
+        for fused in (True, False):
+            ops.FUSE_BN_TAIL = fused
+            fused_calls = []
+            ops.L.call = lambda name, *a: (fused_calls.append(name) if name == "vc_conv_dgrad_bn_tail" else None,
+                                           orig(name, *a))[1]
+            for p in mine.parameters():
+                p.grad = None
+            xm.grad = None
+            out_m.backward(dym.clone(), retain_graph=fused)  # the blocks overwrite the gradient they are handed
             torch.cuda.synchronize()
-        finally:
-            ops.L.call = orig
-            ops.FUSE_BN_TAIL = True
-        # layer1 and layer2 each have one identity block whose input is a residual block's output
-        assert len(fused_calls) == (2 if fused else 0), fused_calls
-        runs[fused] = (f.detach().float().cpu(), {k: p.grad.detach().cpu().clone() for k, p in mine.named_parameters()})
-    tol_o, _ = TOL[torch.bfloat16]
-    # 21 BatchNorm layers deep with statistics over as few as 24 values (layer4 is 2x2 x 6 frames): the features'
-    # L2 error (measured 5.6e-2) is held to twice the bf16 output bound, single elements to four times
-    assert G.l2_rel(runs[True][0], feats) < 2 * tol_o
-    assert G.max_rel(runs[True][0], feats) < 4 * tol_o
-    assert G.l2_rel(runs[True][0], runs[False][0]) < 1e-3
-    worst = max(G.l2_rel(g, runs[False][1][k]) for k, g in runs[True][1].items())
-    assert worst < 2e-2, worst  # measured 1.2e-3
+            assert len(fused_calls) == (1 if fused else 0), fused_calls
+            grads[fused] = {k: p.grad.detach().cpu().clone() for k, p in mine.named_parameters()}
+            grads[fused]["x"] = xm.grad.detach().float().cpu().view(T * B, S, S, 64).permute(0, 3, 1, 2)
+    finally:
+        ops.L.call = orig
+        ops.FUSE_BN_TAIL = True
+    tol_o, tol_g = TOL[torch.bfloat16]
+    om = out_m.detach().float().cpu().view(T * B, S, S, 256).permute(0, 3, 1, 2)
+    assert G.max_rel(om, out_r.detach()) < tol_o
+    grefs["x"] = xr.grad
+    for k, gref in grefs.items():
+        assert G.l2_rel(grads[True][k], gref) < tol_g, (k, G.l2_rel(grads[True][k], gref))
+    diffs = {k: G.l2_rel(gv, grads[False][k]) for k, gv in grads[True].items()}
+    worst = max(diffs.values())
+    assert worst < 1e-2, sorted(diffs.items(), key=lambda kv: -kv[1])[:6]
 
 
 def test_lstm_interlayer_dropout_training(cuda):

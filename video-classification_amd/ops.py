@@ -467,7 +467,7 @@ class GradJoin:
     no separate elementwise add pass runs over the activation."""
 
     def __init__(self, consumers, tail=None):
-        self.pending = consumers
+        self.consumers = self.pending = consumers
         self.buf = None
         self.tail = tail  # BNTail of the residual block whose output this activation is (or None)
 
@@ -476,6 +476,7 @@ class GradJoin:
         self.pending -= 1
         if self.pending == 0:
             self.buf = None
+            self.pending = self.consumers  # armed again: a retained graph may be walked a second time
             return buf
         return None
 
@@ -735,6 +736,8 @@ def _off(t, elems):
 # VC_PERSISTENT_LSTM=0 runs the recurrence as one small GEMM + one cell kernel per time step (A/B, and the
 # path shapes the persistent kernel does not cover fall back to)
 PERSISTENT_LSTM = os.environ.get("VC_PERSISTENT_LSTM", "1") != "0"
+# VC_PERSISTENT_LSTM_BWD=0 keeps only the backward recurrence on the per-step kernels
+PERSISTENT_LSTM_BWD = os.environ.get("VC_PERSISTENT_LSTM_BWD", "1") != "0"
 _lstm_err = {}
 
 
@@ -857,15 +860,30 @@ class _LSTM(torch.autograd.Function):
             Kin = inp.shape[-1]
             need_dinp = l > 0 or ctx.needs_input_grad[0]
             dinp = torch.empty(T, B, Kin, device=dev, dtype=dt) if need_dinp else None
+            dgs = [torch.empty(T, B, 4 * H, device=dev, dtype=dt) for _ in range(dirs)]
+            persist = (PERSISTENT_LSTM and PERSISTENT_LSTM_BWD and
+                       L.query("vc_lstm_persist_bwd_supported", code, B, H, dirs) == 1)
+            if persist:  # the recurrence of every direction of the layer as ONE persistent launch
+                import ctypes
+                nb = L.query("vc_lstm_persist_bwd_xchg_bytes", B, H)
+                xch = [torch.empty(nb, device=dev, dtype=torch.uint8) for _ in range(dirs)]
+                arr = lambda ptrs: (ctypes.c_void_p * len(ptrs))(*ptrs)  # noqa: E731
+                L.call("vc_lstm_persist_bwd", code,
+                       arr([dlayer.data_ptr() + d * H * dlayer.element_size() for d in range(dirs)]), H * dirs,
+                       arr([per_dir[d][2].data_ptr() for d in range(dirs)]),
+                       arr([per_dir[d][1].data_ptr() for d in range(dirs)]),
+                       arr([per_dir[d][4].data_ptr() for d in range(dirs)]),
+                       arr([g_.data_ptr() for g_ in dgs]), arr([x_.data_ptr() for x_ in xch]),
+                       L.ptr(lstm_error_flag(dev)), T, B, H, dirs, st)
             for d in range(dirs):
                 _, c, act, wih_t, whh_t = per_dir[d]
                 w_ih, w_hh, b_ih, b_hh = params[(l * dirs + d) * 4:(l * dirs + d) * 4 + 4]
-                dg = torch.empty(T, B, 4 * H, device=dev, dtype=dt)
+                dg = dgs[d]
                 dh_rec = torch.empty(B, H, device=dev, dtype=f32)
                 dc = [torch.empty(B, H, device=dev, dtype=f32), torch.empty(B, H, device=dev, dtype=f32)]
                 order = list(range(T)) if d == 0 else list(range(T - 1, -1, -1))
                 nxt = None  # the step processed after t in forward order (whose gradients flow back into t)
-                for k in range(T - 1, -1, -1):
+                for k in (range(T - 1, -1, -1) if not persist else ()):
                     t = order[k]
                     prev = order[k - 1] if k > 0 else None
                     if nxt is not None:
