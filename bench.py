@@ -258,6 +258,14 @@ def main():
                                   for k, v in fam.items() if v[1] > 0},
                 "measured": prof_where}
 
+    # whole-step figure of the metric's "% MFMA peak": algorithmic FLOPs of the model (3 x forward for a training
+    # step) at the measured rate, per GPU, against the dense bf16 peak
+    from video_classification_amd import flops as FL
+    fwd_flops = FL.flops_per_clip(model, 16, shape[-2], shape[-1])
+    step_tflops = 3.0 * fwd_flops * B * args.steps / elapsed / 1e12
+    whole_step = {"forward_gflop_per_clip": fwd_flops / 1e9, "train_tflops_per_gpu": step_tflops,
+                  "frac_of_mfma_peak": step_tflops / MFMA_BF16_PEAK_TFLOPS,
+                  "note": "3 x forward FLOPs (convolution, linear, LSTM and attention products) x clips/s per GPU"}
     if rank == 0:
         line = {
             "metric": "train clips/sec (16x224^2 UCF101 shape)",
@@ -277,6 +285,7 @@ def main():
                        "launch": mode},
             "loss": float(loss.detach()),
             "roofline": roof,
+            "whole_step": whole_step,
             "cpu_baseline": None,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -76,10 +76,10 @@ def swin_flops(sw, H, W):
             total += linear_flops(stage.downsample.reduction, h * w)
         for blk in stage.blocks:
             n = h * w
-            total += linear_flops(blk.attn_qkv, n) + linear_flops(blk.attn_proj, n)
-            total += linear_flops(blk.mlp_fc1, n) + linear_flops(blk.mlp_fc2, n)
+            total += linear_flops(blk.attn.qkv, n) + linear_flops(blk.attn.proj, n)
+            total += linear_flops(blk.mlp.fc1, n) + linear_flops(blk.mlp.fc2, n)
             ws2 = blk.ws * blk.ws
-            total += 2.0 * 2.0 * n * ws2 * blk.dim   # QK^T and PV: per token ws^2 keys x head_dim x heads
+            total += 2.0 * 2.0 * n * ws2 * blk.attn.proj.in_features   # QK^T and PV: per token ws^2 keys x dim
     return total
 
 
