@@ -169,20 +169,25 @@ __global__ __launch_bounds__(LTHR, 1) void lstm_persist_fwd_kernel(LstmArgs a) {
 // ---------------------------------------------------------------------------------------------------------
 // Backward recurrence (BPTT), same sharding: a workgroup owns 16 hidden units.  Per step it needs
 //   dh_rec[b][j] = sum_r dgates_next[b][r] * W_hh[r][j]        (r over the 4H gate rows)
-// for its 16 units j, i.e. the COMPLETE gate-gradient vector of the step processed before (4x the data the
-// forward pass exchanges).  The owner of (b, unit) computes the unit's four gate gradients in registers from
-// dh = dh_out + dh_rec, the carried dc and the saved activations, stores them to dgates (the sequence-wide
-// weight / input gradient GEMMs read them afterwards) and publishes them as tagged granules.  The reduction
-// index is ordered k = gate*H + unit, the order of a row of W_hh^T, so a wave's A fragments are 16-byte loads
-// of W_hh^T [H][4H]; the four waves split k and their 16x32 partial products are summed through LDS.
+// for its 16 units j, i.e. the COMPLETE gate-gradient vector of the step processed before: 4x the data the
+// forward pass exchanges, too much for 8-byte tagged granules (every small write-through store is a fabric write
+// of its own).  It travels as bulk data instead: the owner of (b, unit) computes the unit's four gate gradients in
+// registers (dh = dh_out + dh_rec, the carried dc, the saved activations), the workgroup collects its 32 x 64
+// values in LDS and writes them as whole 128-byte lines with write-through 16-byte stores, every wave drains its
+// stores, and ONE lane then raises the workgroup's flag to the step number.  A consumer polls the flags of all
+// producers (one wave, one lane per flag, L1-bypassing loads), passes a barrier and fetches the vector with
+// L1-bypassing 16-byte loads: no fence on either side.  Two parities of the data buffer suffice: nobody can
+// publish step s+2 before everybody has read step s.
+// The reduction index is ordered k = 4*unit + gate (a workgroup's 64 values are contiguous); the four waves split
+// k, each holding its slice of W_hh^T as MFMA A fragments in registers, and sum their 16 x 32 partials through LDS.
 // ---------------------------------------------------------------------------------------------------------
 struct LstmBwdDir {
   const bf16* dh_out;   // gradient of the layer output: dh_out[(t*B + b)*ldo + unit]
   const float* act;     // [T][B][4H] post-activation gates saved by the forward pass
   const float* c;       // [T][B][H]
-  const bf16* w_hh_t;   // [H][4H]: W_hh^T
+  const bf16* w_hh_t;   // [H][4H]: W_hh^T (columns gate-major, as W_hh's rows)
   bf16* dgates;         // [T][B][4H], gate-major like act
-  unsigned long long* xchg;  // [chunks][2 parities][2H * 32] granules
+  unsigned char* xchg;  // per batch chunk: data [2 parities][32][4H] bf16, then 64 flag words
   int reverse;
 };
 struct LstmBwdArgs {
@@ -192,12 +197,18 @@ struct LstmBwdArgs {
   int* err;
 };
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) unsigned gu32;
+constexpr int BWD_FLAG_WORDS = 64;
+
 template <int NKS>  // NKS = H / 32 = k-steps of the recurrent product per wave (4H / 32 in all)
 __global__ __launch_bounds__(LTHR, 1) void lstm_persist_bwd_kernel(LstmBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   constexpr int H = NKS * 32, K = 4 * H;
-  bf16* sD = reinterpret_cast<bf16*>(lds_raw);                    // [32][K] gate gradients of the previous step
-  float* sR = reinterpret_cast<float*>(lds_raw + (size_t)BCHUNK * K * sizeof(bf16));  // [4][16][32] partials
+  constexpr int NCHK = K / 8;  // 16-byte chunks per row of the gate-gradient vector
+  bf16* sD = reinterpret_cast<bf16*>(lds_raw);                                         // [32][K], chunks swizzled by row
+  float* sR = reinterpret_cast<float*>(lds_raw + (size_t)BCHUNK * K * sizeof(bf16));  // [4][16][32] partial products
+  bf16* sP = reinterpret_cast<bf16*>(sR + 4 * 16 * 32);                                // [32][64] this workgroup's values
   const LstmBwdDir D = blockIdx.y ? a.d[1] : a.d[0];  // a runtime index would put the struct in scratch
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -207,21 +218,29 @@ __global__ __launch_bounds__(LTHR, 1) void lstm_persist_bwd_kernel(LstmBwdArgs a
   const int unit = u0 + 4 * wave + q;
   const int bv = 1 << a.bvs;
   const int ntile = bv > 16 ? 2 : 1;  // batch tiles of 16 that carry data
+  const int nprod = H / UNITS;        // workgroups that publish to this one (itself included)
 
-  // this wave's slice of W_hh^T: rows = the workgroup's 16 units, k in [wave*H, (wave+1)*H)
+  // this wave's slice of W_hh^T: rows = the workgroup's 16 units, k = 4*unit' + gate in [wave*H, (wave+1)*H)
   bf16x8 wreg[NKS];
   {
-    const bf16* wrow = D.w_hh_t + (size_t)(u0 + l15) * K + wave * H + 8 * q;
+    const bf16* wrow = D.w_hh_t + (size_t)(u0 + l15) * K;
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) wreg[ks] = *reinterpret_cast<const bf16x8*>(wrow + 32 * ks);
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int ub = (wave * H + 32 * ks + 8 * q) >> 2;  // first of the two units this fragment covers
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wreg[ks][e] = wrow[(e & 3) * H + ub + (e >> 2)];
+    }
   }
   // rows that are never exchanged stay zero for the whole kernel
   for (int i = tid; i < BCHUNK * K / 8; i += LTHR) reinterpret_cast<bf16x8*>(sD)[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
   __syncthreads();
 
-  gu64* xbase = (gu64*)(D.xchg + (size_t)blockIdx.z * 2 * (K / 2) * BCHUNK);
-  const int per_parity = (K / 2) * BCHUNK;
-  const int ng = (K / 2 * bv) / LTHR;  // granules per thread per step (>= 1: K/2*bv >= 64*8*... see host check)
+  const size_t data_bytes = (size_t)2 * BCHUNK * K * sizeof(bf16);
+  unsigned char* xb = D.xchg + (size_t)blockIdx.z * (data_bytes + BWD_FLAG_WORDS * 4);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(xb, 0, (int)data_bytes, 0x00020000);
+  gu32* flags = (gu32*)(xb + data_bytes);
+  const int parity_bytes = BCHUNK * K * (int)sizeof(bf16);
+  const int nload = (bv * NCHK + LTHR - 1) / LTHR;  // 16-byte loads per thread per step
 
   float dcar[2] = {0.f, 0.f};  // dc flowing into the step being processed (dc_next * f_next)
   for (int ts = 0; ts < a.T; ++ts) {
@@ -246,33 +265,36 @@ __global__ __launch_bounds__(LTHR, 1) void lstm_persist_bwd_kernel(LstmBwdArgs a
     }
     float dhr[2] = {0.f, 0.f};
     if (ts > 0) {
-      gu64* xp = xbase + ((ts - 1) & 1) * per_parity;
-      for (int base = 0; base < ng; base += 32) {
-        unsigned long long g[32];
+      if (wave == 0) {  // one wave polls, one lane per producer; the flags only grow
         unsigned spins = 0;
         for (;;) {
-#pragma unroll
-          for (int k = 0; k < 32; ++k)
-            if (base + k < ng) g[k] = __hip_atomic_load(xp + tid + LTHR * (base + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          bool ok = true;
-#pragma unroll
-          for (int k = 0; k < 32; ++k)
-            if (base + k < ng) ok &= (unsigned)(g[k] >> 32) == (unsigned)ts;
-          if (ok) break;
+          unsigned f = (unsigned)ts;
+          if (lane < nprod) f = __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (__all(f >= (unsigned)ts)) break;
           if (++spins > SPIN_LIMIT) {
             if (a.err) atomicExch(a.err, 1);
             break;
           }
           __builtin_amdgcn_s_sleep(1);
         }
+      }
+      __syncthreads();
+      const int pbase = ((ts - 1) & 1) * parity_bytes;
+      constexpr int LB = 16;  // loads in flight per thread and batch
+      for (int base = 0; base < nload; base += LB) {
+        u32x4 v[LB];
 #pragma unroll
-        for (int k = 0; k < 32; ++k) {
-          if (base + k < ng) {
-            const int idx = tid + LTHR * (base + k);
-            const int kp = idx >> a.bvs, b = idx & (bv - 1);  // k pair, batch row
-            const int kk = 2 * kp;
-            const int chunk = (kk >> 3) ^ (b & 15);
-            *reinterpret_cast<unsigned*>(sD + b * K + chunk * 8 + (kk & 7)) = (unsigned)g[k];
+        for (int k = 0; k < LB; ++k) {
+          const int idx = tid + LTHR * (base + k);
+          if (base + k < nload && idx < bv * NCHK)
+            v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, pbase + idx * 16, 0, 16);
+        }
+#pragma unroll
+        for (int k = 0; k < LB; ++k) {
+          const int idx = tid + LTHR * (base + k);
+          if (base + k < nload && idx < bv * NCHK) {
+            const int b = idx / NCHK, ch = idx - b * NCHK;
+            *reinterpret_cast<u32x4*>(sD + b * K + ((ch ^ (b & 15)) << 3)) = v[k];
           }
         }
       }
@@ -301,57 +323,44 @@ __global__ __launch_bounds__(LTHR, 1) void lstm_persist_bwd_kernel(LstmBwdArgs a
 #pragma unroll
         for (int w = 0; w < 4; ++w) dhr[bt] += sR[(w * 16 + 4 * wave + q) * 32 + bt * 16 + l15];
     }
-    float dgv[2][4];
 #pragma unroll
     for (int bt = 0; bt < 2; ++bt) {
-      const int b = b0 + bt * 16 + l15;
       const float dh = dho[bt] + dhr[bt];
       const float tc = tanhf(cc[bt]);
       const float dc = dh * go[bt] * (1.f - tc * tc) + dcar[bt];
       dcar[bt] = dc * gf[bt];
-      dgv[bt][0] = dc * gg[bt] * gi[bt] * (1.f - gi[bt]);
-      dgv[bt][1] = dc * cp[bt] * gf[bt] * (1.f - gf[bt]);
-      dgv[bt][2] = dc * gi[bt] * (1.f - gg[bt] * gg[bt]);
-      dgv[bt][3] = dh * tc * go[bt] * (1.f - go[bt]);
-      if (b < a.B && bt < ntile) {
-        bf16* dp = D.dgates + ((size_t)t * a.B + b) * K + unit;
+      bf16x4 dg4;  // i, f, g, o; rows beyond B hold zeros (their activations were read as zeros)
+      dg4[0] = (bf16)(dc * gg[bt] * gi[bt] * (1.f - gi[bt]));
+      dg4[1] = (bf16)(dc * cp[bt] * gf[bt] * (1.f - gf[bt]));
+      dg4[2] = (bf16)(dc * gi[bt] * (1.f - gg[bt] * gg[bt]));
+      dg4[3] = (bf16)(dh * tc * go[bt] * (1.f - go[bt]));
+      *reinterpret_cast<bf16x4*>(sP + (bt * 16 + l15) * 64 + (4 * wave + q) * 4) = dg4;
+    }
+    __syncthreads();
+    {
+      // this workgroup's 32 x 64 values: (a) one 128-byte line per batch row to the exchange buffer, (b) per gate
+      // 16 units = 32 bytes to dgates (gate-major), which the sequence-wide GEMMs read after the kernel
+      const int row = tid >> 3, c8 = tid & 7;
+      if (has_prev && row < bv) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(sP + row * 64 + c8 * 8);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (ts & 1) * parity_bytes + (row * K + 4 * u0 + c8 * 8) * 2, 0, 16);
+      }
+      const int g4 = c8 >> 1, half = c8 & 1;
+      const int b = b0 + row;
+      if (b < a.B && row < bv) {
+        bf16x8 o;
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) dp[g4 * H] = (bf16)dgv[bt][g4];
-      } else {
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) dgv[bt][g4] = 0.f;
+        for (int e = 0; e < 8; ++e) o[e] = sP[row * 64 + (8 * half + e) * 4 + g4];
+        *reinterpret_cast<bf16x8*>(D.dgates + ((size_t)t * a.B + b) * K + g4 * H + u0 + 8 * half) = o;
       }
     }
-    if (ts + 1 < a.T) {
-      // publish: a granule holds one gate of two adjacent units (even unit low); the even-unit lane sends
-      // gates i and f, its odd neighbour (lane ^ 16) sends g and o
-      gu64* xp = xbase + (ts & 1) * per_parity;
-#pragma unroll
-      for (int bt = 0; bt < 2; ++bt) {
-        float other[4];
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) other[g4] = __shfl_xor(dgv[bt][g4], 16, 64);
-        const int bl = bt * 16 + l15;
-        if (bl < bv) {
-#pragma unroll
-          for (int h2 = 0; h2 < 2; ++h2) {
-            const int g4 = (q & 1) * 2 + h2;
-            union {
-              bf16 h[2];
-              unsigned u;
-            } pk;
-            // static register indices only (a lane-dependent index would send the arrays to scratch)
-            pk.h[0] = (bf16)((q & 1) ? other[2 + h2] : dgv[bt][h2]);
-            pk.h[1] = (bf16)((q & 1) ? dgv[bt][2 + h2] : other[h2]);
-            const int kp = (g4 * H + (unit & ~1)) >> 1;
-            const unsigned long long gr = ((unsigned long long)(unsigned)(ts + 1) << 32) | pk.u;
-            __hip_atomic_store(xp + (kp << a.bvs) + bl, gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        }
-      }
+    if (has_prev) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // EVERY storing wave drains its write-through stores
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(flags + blockIdx.x, (unsigned)(ts + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      __syncthreads();  // sP is rewritten by the next step
     }
-    // the next step's gather overwrites sD and its partials overwrite sR: both are behind barriers every wave
-    // passes after its last read (the one before the partial sums, and the one after the next gather)
   }
 }
 
@@ -438,7 +447,7 @@ int vc_lstm_persist_fwd(int dtype, const float* const* gates_x, const void* cons
 // ---- backward ----
 long long vc_lstm_persist_bwd_xchg_bytes(int B, int H) {
   const long long chunks = (B + BCHUNK - 1) / BCHUNK;
-  return chunks * 2 * (2LL * H) * BCHUNK * 8;
+  return chunks * (2LL * BCHUNK * 4 * H * (long long)sizeof(bf16) + BWD_FLAG_WORDS * 4);
 }
 
 // 1 if the backward recurrence of (B, H, ndir) can run as one persistent launch: H a power of two in 32..512
@@ -475,7 +484,7 @@ int vc_lstm_persist_bwd(int dtype, const void* const* dh_out, int ldo, const flo
     a.d[d].c = c[d];
     a.d[d].w_hh_t = (const bf16*)w_hh_t[d];
     a.d[d].dgates = (bf16*)dgates[d];
-    a.d[d].xchg = (unsigned long long*)xchg[d];
+    a.d[d].xchg = (unsigned char*)xchg[d];
     a.d[d].reverse = d;
     if (hipMemsetAsync(xchg[d], 0, (size_t)xb, stream) != hipSuccess) {
       vc_set_error("vc_lstm_persist_bwd: hipMemsetAsync failed");
@@ -484,7 +493,8 @@ int vc_lstm_persist_bwd(int dtype, const void* const* dh_out, int ldo, const flo
   }
   if (ndir == 1) a.d[1] = a.d[0];
   const dim3 grid(H / UNITS, ndir, (B + BCHUNK - 1) / BCHUNK);
-  const size_t lds = (size_t)BCHUNK * 4 * H * sizeof(bf16) + 4 * 16 * 32 * sizeof(float);
+  size_t lds = (size_t)BCHUNK * 4 * H * sizeof(bf16) + 4 * 16 * 32 * sizeof(float) + BCHUNK * 64 * sizeof(bf16);
+  if (lds < 84 * 1024) lds = 84 * 1024;  // one workgroup per CU, the configuration the flag hand-off was validated in
   int rc;
   switch (H / 32) {
     case 1: rc = launch_lstm_bwd<1>(a, grid, lds, stream); break;
