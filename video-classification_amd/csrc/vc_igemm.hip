@@ -1421,6 +1421,16 @@ int wgrad_target_blocks() {
   return v;
 }
 
+// fewest pixel rows one split of the weight gradient should cover (VC_WGRAD_SPLIT_ROWS overrides, for tuning runs)
+int wgrad_min_rows_per_split() {
+  static const int v = [] {
+    const char* e = getenv("VC_WGRAD_SPLIT_ROWS");
+    const int n = e ? atoi(e) : 0;
+    return n > 0 ? n : 2048;
+  }();
+  return v;
+}
+
 bool nt_persist_eligible(const ConvGeom& g, int dtype) {
   const bool single_tap = g.kd * g.kh * g.kw == 1;
   return dtype == VC_BF16 && use_glds() && g.ldi % 8 == 0 && g.K >= 8 && nt_variant() == 2 &&
@@ -1614,6 +1624,11 @@ int vc_conv_wgrad(const int* desc, int dtype, const void* x, int ldx, const void
     int splits = ceil_div(wgrad_target_blocks() * (tco + tcol < 256 ? 3 : 2) / 2, ntiles);
     const int max_splits = ceil_div(g.M, BK);
     if (splits > max_splits) splits = max_splits;
+    // Every split adds the whole fp32 weight tile with atomics (about 1.3 TB/s chip-wide): a split must bring
+    // enough rows for its products to outweigh that, which depends on the row count alone (both scale with Co*K).
+    // Matters for short, wide layers (Swin stages 3-4, ResNet layer4): fewer, longer workgroups win there.
+    const int split_cap = g.M / wgrad_min_rows_per_split() > 2 ? g.M / wgrad_min_rows_per_split() : 2;
+    if (splits > split_cap) splits = split_cap;
     if (splits < 1) splits = 1;
     int mps = ceil_div(ceil_div(g.M, splits), BK) * BK;
     splits = ceil_div(g.M, mps);
