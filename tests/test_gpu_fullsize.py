@@ -1,0 +1,196 @@
+"""GPU parity at the shapes BASELINE.json quotes: clips of 16 x 3 x 224 x 224 (Conv3D: 1 x 16 x 112 x 112), 101
+classes, full-width models, against the CPU oracle with identical weights and inputs -- logits, loss, predictions,
+every parameter gradient.  The oracle's forward + backward takes about 10 s per model on 8-16 host cores.
+
+  ResNetCRNN   ResCNNEncoder(ResNet-50 trunk, 1024/768/512) + DecoderRNN(2 x 512, FC 256), configs[1], 6 clips
+  clusterSwin  ClusterSwinEncoder(Swin-T, E = 96, k = 8) + TCG_LSTM(H = 512, L = 2), configs[4], 4 clips
+  Conv3D       Conv3DModel at its native 1 x 16 x 112 x 112, configs[2], 4 clips
+
+The ResNet trunk and the Swin-T backbone restate third-party architectures (torchvision / timm are absent from the
+reference checkout and this image): these tests hold the HIP path to the oracle's restatement of them.
+
+Tolerances.  Outputs: max error relative to the largest reference logit, 2e-4 in fp32 and 4e-2 in bf16 (measured
+7e-7 / 4e-3 at worst).  Gradients: L2 error relative to the tensor's norm, bounds stated at each test from the
+measured error and the conditioning of the model (BatchNorm over few samples amplifies any rounding: the tests say
+how much the oracle's OWN gradients move when only its input is rounded to bf16).  Predictions: equal in fp32; in
+bf16 equal wherever the reference's own top-2 margin exceeds twice the output bound."""
+import functools
+import types
+
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import golden_util as G
+
+pytestmark = pytest.mark.gpu
+DTYPES = [torch.float32, torch.bfloat16]
+IDS = ["f32", "bf16"]
+
+
+def _compare(mine, out_m, loss_m, ref_out, ref_loss, ref_grads, dt, tol_g, cancelled=(), group_tol=None):
+    tol_o = 2e-4 if dt == torch.float32 else 4e-2
+    out_m = out_m.detach().float().cpu()
+    err_o = G.max_rel(out_m, ref_out)
+    errs = {}
+    for k, p in mine.named_parameters():
+        if any(k.endswith(c) for c in cancelled):
+            continue
+        errs[k] = G.l2_rel(p.grad.detach().cpu(), ref_grads[k])
+    worst = max(errs, key=errs.get)
+    groups = {}
+    for k, e in errs.items():
+        gk = ".".join(k.split(".")[:2])
+        groups[gk] = max(groups.get(gk, 0.0), e)
+    print("\n  worst gradient error per group:", {k: float(f"{v:.2e}") for k, v in groups.items()})
+    print(f"\n[{'f32' if dt == torch.float32 else 'bf16'}] logits max-rel {err_o:.3e}, loss {loss_m:.6f} vs {ref_loss:.6f}, "
+          f"worst gradient {worst} {errs[worst]:.3e}, median {sorted(errs.values())[len(errs) // 2]:.3e}")
+    assert err_o < tol_o
+    assert abs(loss_m - ref_loss) < (1e-4 if dt == torch.float32 else 2e-2)
+    if dt == torch.float32:
+        assert torch.equal(out_m.argmax(1), ref_out.argmax(1))
+    else:
+        top2 = ref_out.topk(2, dim=1).values
+        safe = (top2[:, 0] - top2[:, 1]) > 2 * tol_o * ref_out.abs().max()
+        assert torch.equal(out_m.argmax(1)[safe], ref_out.argmax(1)[safe])
+    assert errs[worst] < tol_g, (worst, errs[worst])
+    for prefix, bound in (group_tol or {}).items():  # tighter bounds for the tensors near the loss
+        for k, e in errs.items():
+            if k.startswith(prefix):
+                assert e < bound, (k, e, bound)
+    for c in cancelled:  # biases straight into a BatchNorm: the true gradient is zero, both sides hold rounding noise
+        for k, p in mine.named_parameters():
+            if k.endswith(c):
+                wk = k[:-len("bias")] + "weight"
+                assert p.grad.abs().max().item() <= tol_g * ref_grads[wk].abs().max().item(), k
+
+
+@functools.lru_cache(maxsize=None)
+def _resnet_ref():
+    from oracle import torch_oracle as O
+    cfg = types.SimpleNamespace(CNN_fc_hidden1=1024, CNN_fc_hidden2=768, CNN_embed_dim=512, dropout_p=0.0,
+                                use_pretrained=False, RNN_hidden_layers=2, RNN_hidden_nodes=512, RNN_FC_dim=256,
+                                num_classes=101, arch="resnet50")
+    torch.manual_seed(11)
+    ref = O.ResNetCRNNModel(cfg)
+    with torch.no_grad():  # residual branches damped, as in a trained network (see the test's docstring)
+        for n, p in ref.named_parameters():
+            if n.endswith("bn3.weight"):
+                p.fill_(0.1)
+    g = torch.Generator().manual_seed(1234)
+    B = 6
+    # image-like clips: a smooth random picture per frame (8 x 8 noise upsampled), a colour cast, fine noise
+    low = F.interpolate(torch.randn(B * 16, 3, 8, 8, generator=g), size=(224, 224), mode="bilinear", align_corners=False)
+    x = (1.5 * low + torch.randn(B * 16, 3, 1, 1, generator=g) +
+         0.3 * torch.randn(B * 16, 3, 224, 224, generator=g)).view(B, 16, 3, 224, 224)
+    y = torch.randint(0, 101, (B, 1), generator=g)
+    ref.train()
+    out = ref(x)
+    loss = nn.CrossEntropyLoss()(out, y.squeeze(1))
+    loss.backward()
+    return cfg, ref.state_dict(), x, y, out.detach(), loss.item(), {k: p.grad for k, p in ref.named_parameters()}
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("dt", DTYPES, ids=IDS)
+def test_resnet50_crnn_ucf_shape(cuda, dt):
+    """Conditioning decides what can be asked here.  With torchvision's default initialisation (every bn3.weight = 1)
+    and white-noise clips the oracle itself is chaotic: rounding only the input clip to bf16 moves ITS logits by 3 %
+    and its gradients by 12-136 % (50 un-damped residual blocks, then BatchNorm1d over 6 nearly identical pooled
+    features per time step).  The test therefore uses image-like clips and bn3.weight = 0.1 (residual branches
+    damped, as training leaves them); the oracle's sensitivity to bf16 input rounding is then 6e-4 on the logits,
+    2e-3 (decoder) to 5e-2 (LSTM, fc3) to 0.1-0.2 (trunk) on the gradients.  Gradient bounds: fp32 2e-2, bf16 0.5."""
+    from video_classification_amd import modules as M
+    from video_classification_amd import ops
+    cfg, sd, x, y, ref_out, ref_loss, ref_grads = _resnet_ref()
+    mine = M.ResNetCRNNModel(cfg)
+    mine.load_state_dict(sd, strict=True)
+    mine.to(cuda).set_compute_dtype(dt)
+    mine.train()
+    out = mine(x.to(cuda))
+    loss = ops.cross_entropy(out, y.to(cuda))
+    loss.backward()
+    torch.cuda.synchronize()
+    ops.check_lstm_error()
+    f32 = dt == torch.float32
+    # measured: fp32 trunk 7e-3, head and decoder < 1e-5; bf16 decoder.fc2 9e-3, decoder 5e-2, head 0.25, trunk 0.40
+    _compare(mine, out, loss.item(), ref_out, ref_loss, ref_grads, dt, 2e-2 if f32 else 0.7,
+             cancelled=["encoder.fc1.bias", "encoder.fc2.bias"],
+             group_tol={"decoder.": 1e-4, "encoder.fc": 1e-4, "encoder.bn": 1e-4} if f32 else
+             {"decoder.fc2": 3e-2, "decoder.": 0.12})
+
+
+@functools.lru_cache(maxsize=None)
+def _swin_ref():
+    from oracle import torch_oracle as O
+    torch.manual_seed(12)
+    ref = O.SwinTCGModel(O.ClusterSwinEncoder(embed_dim=96, k_tokens=8), O.TCG_LSTM(96, 512, 2, 8, 4, 101, 0.0))
+    g = torch.Generator().manual_seed(4321)
+    x = torch.randn(4, 16, 3, 224, 224, generator=g)
+    y = torch.randint(0, 101, (4, 1), generator=g)
+    ref.train()
+    out = ref(x)
+    loss = nn.CrossEntropyLoss()(out, y.squeeze(1))
+    loss.backward()
+    return ref.state_dict(), x, y, out.detach(), loss.item(), {k: p.grad for k, p in ref.named_parameters()}
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("dt", DTYPES, ids=IDS)
+def test_cluster_swin_tcg_ucf_shape(cuda, dt):
+    """No batch statistics anywhere in this model (LayerNorm trunk, no BatchNorm head): the best-conditioned of the
+    three, and the tightest bounds: gradients 1e-4 in fp32, 5e-2 in bf16."""
+    from video_classification_amd import modules as M
+    from video_classification_amd import ops
+    from video_classification_amd import swin as S
+    sd, x, y, ref_out, ref_loss, ref_grads = _swin_ref()
+    mine = M.SwinTCGModel(S.ClusterSwinEncoder(embed_dim=96, k_tokens=8), M.TCG_LSTM(96, 512, 2, 8, 4, 101, 0.0))
+    mine.load_state_dict(sd, strict=True)
+    mine.to(cuda).set_compute_dtype(dt)
+    mine.train()
+    out = mine(x.to(cuda))
+    loss = ops.cross_entropy(out, y.to(cuda))
+    loss.backward()
+    torch.cuda.synchronize()
+    ops.check_lstm_error()
+    # measured: fp32 worst 8e-6 (patch embedding); bf16 worst 1.5e-2 (a stage-4 bias table), decoder 7e-3
+    _compare(mine, out, loss.item(), ref_out, ref_loss, ref_grads, dt, 1e-4 if dt == torch.float32 else 5e-2)
+
+
+@functools.lru_cache(maxsize=None)
+def _conv3d_ref():
+    from oracle import torch_oracle as O
+    torch.manual_seed(13)
+    ref = O.Conv3DModel(G.conv3d_config())
+    g = torch.Generator().manual_seed(999)
+    x = torch.randn(4, 1, 16, 112, 112, generator=g)
+    y = torch.randint(0, 101, (4, 1), generator=g)
+    ref.train()
+    out = ref(x)
+    loss = nn.CrossEntropyLoss()(out, y.squeeze(1))
+    loss.backward()
+    return ref.state_dict(), x, y, out.detach(), loss.item(), {k: p.grad for k, p in ref.named_parameters()}
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=IDS)
+def test_conv3d_native_shape(cuda, dt):
+    """Gradient bounds 1e-2 in fp32, 0.5 in bf16 for the convolution stack; 1e-5 / 0.12 for the classifier."""
+    from video_classification_amd import modules as M
+    from video_classification_amd import ops
+    sd, x, y, ref_out, ref_loss, ref_grads = _conv3d_ref()
+    mine = M.Conv3DModel(G.conv3d_config())
+    mine.load_state_dict(sd, strict=True)
+    mine.to(cuda).set_compute_dtype(dt)
+    mine.train()
+    out = mine(x.to(cuda))
+    loss = ops.cross_entropy(out, y.to(cuda))
+    loss.backward()
+    torch.cuda.synchronize()
+    # The global average pool hands every position of a sample the same gradient, and each BatchNorm backward
+    # removes its mean: heavy cancellation, so rounding is amplified layer by layer towards the input (measured
+    # fp32: 6e-7 at the classifier, 8e-4 at the last convolution, 3e-3 at the first; bf16: 3e-3, 8e-2, 0.22).
+    f32 = dt == torch.float32
+    _compare(mine, out, loss.item(), ref_out, ref_loss, ref_grads, dt, 1e-2 if f32 else 0.5,
+             cancelled=[f"conv3d.{i}.bias" for i in (0, 4, 8, 12)],
+             group_tol={"fc.": 1e-5} if f32 else {"fc.4": 2e-2, "fc.": 0.12})
