@@ -66,6 +66,16 @@ int vc_conv_dgrad(const int* desc, int dtype, const void* dy, int lddy, const vo
 int vc_conv_dgrad_bn_tail_supported(const int* desc, int dtype);
 int vc_conv_dgrad_bn_tail(const int* desc, int dtype, const void* dy, const void* w_packed_t, void* dx, int beta,
                           const void* tail_y, const uint8_t* tail_bits, float* bn_partial, vc_stream_t stream);
+/* GEMM epilogues that read a side tensor of the output's own layout (bf16, dense rows, more than 64 output columns;
+ * vc_conv_epilogue_side_supported(desc, dtype, mode: 0 forward, 1 data gradient) says whether a geometry qualifies):
+ * vc_conv_fwd_residual: y = conv(x) + bias + residual, out of place -- the x + attn(x) / x + mlp(x) of the Swin blocks
+ * (timm SwinTransformerBlock behind model_components.py:254, 412); vc_conv_dgrad_gelu: dx = dgrad * gelu'(pre), the
+ * gradient through the MLP's GELU taken in the data-gradient GEMM of mlp.fc2 (pre = mlp.fc1's output). */
+int vc_conv_epilogue_side_supported(const int* desc, int dtype, int mode);
+int vc_conv_fwd_residual(const int* desc, int dtype, const void* x, const void* w_packed, const float* bias,
+                         const void* residual, void* y, vc_stream_t stream);
+int vc_conv_dgrad_gelu(const int* desc, int dtype, const void* dy, const void* w_packed_t, const void* pre, void* dx,
+                       vc_stream_t stream);
 /* dw_packed (fp32 [co][taps][ci]) is accumulated into with atomics: the caller zeroes it.  dbias (nullable, fp32
  * [co]) receives += the column sums of dy, i.e. the bias gradient of the same layer, from the same pass over dy. */
 int vc_conv_wgrad(const int* desc, int dtype, const void* x, int ldx, const void* dy, int lddy, float* dw_packed,

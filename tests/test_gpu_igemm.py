@@ -222,3 +222,39 @@ def test_conv_dgrad_with_bn_tail(cuda, shape, beta):
         assert torch.equal(dx0, dx1)  # the separate pass masked its copy in place
         assert _rel(sa[0].cpu(), sb[0].cpu()) < 1e-5
         assert _rel(sa[1].cpu(), sb[1].cpu()) < 1e-4
+
+
+def test_epilogue_side_tensor_forms(cuda):
+    """vc_conv_fwd_residual == vc_conv_fwd followed by an add of the residual (one rounding of the sum instead of
+    two: within one bf16 ulp of the unfused pair), vc_conv_dgrad_gelu == vc_conv_dgrad times gelu'(pre) computed
+    in fp32 from the unfused result."""
+    from video_classification_amd import _lib as L
+    g = torch.Generator().manual_seed(21)
+    M, K, N = 777, 192, 384   # ragged row count, two k-tiles, three column tiles
+    x = torch.randn(M, K, generator=g).to(cuda, torch.bfloat16)
+    wf = (torch.randn(N, 1, K, generator=g) * 0.1).to(cuda, torch.bfloat16)
+    bias = torch.randn(N, generator=g).to(cuda)
+    res = torch.randn(M, N, generator=g).to(cuda, torch.bfloat16)
+    desc = L.int_array([M, 1, 1, 1, K, 1, 1, 1, N, 1, 1, 1, 1, 1, 1, 0, 0, 0])
+    assert L.query("vc_conv_epilogue_side_supported", desc, 1, 0) == 1
+    y0 = torch.empty(M, N, device=cuda, dtype=torch.float32)
+    y1 = torch.empty(M, N, device=cuda, dtype=torch.bfloat16)
+    L.call("vc_conv_fwd", desc, 1, L.ptr(x), 0, L.ptr(wf), L.ptr(bias), L.ptr(y0), 0, 0, 1, 0, L.stream())
+    L.call("vc_conv_fwd_residual", desc, 1, L.ptr(x), L.ptr(wf), L.ptr(bias), L.ptr(res), L.ptr(y1), L.stream())
+    torch.cuda.synchronize()
+    ref = y0.bfloat16().float() + res.float()  # the kernel parks the bf16-rounded result, then adds in fp32
+    assert torch.equal(y1, ref.bfloat16())
+    # data gradient of a layer K -> N: dy [M, N] -> dx [M, K], K = 192 > 64 columns
+    dy = torch.randn(M, N, generator=g).to(cuda, torch.bfloat16)
+    wt = (torch.randn(K, 1, N, generator=g) * 0.1).to(cuda, torch.bfloat16)
+    pre = torch.randn(M, K, generator=g).to(cuda, torch.bfloat16)
+    assert L.query("vc_conv_epilogue_side_supported", desc, 1, 1) == 1
+    d0 = torch.empty(M, K, device=cuda, dtype=torch.bfloat16)
+    d1 = torch.empty(M, K, device=cuda, dtype=torch.bfloat16)
+    L.call("vc_conv_dgrad", desc, 1, L.ptr(dy), 0, L.ptr(wt), L.ptr(d0), 0, 0, 0, L.stream())
+    L.call("vc_conv_dgrad_gelu", desc, 1, L.ptr(dy), L.ptr(wt), L.ptr(pre), L.ptr(d1), L.stream())
+    torch.cuda.synchronize()
+    p = pre.float().cpu().double()
+    gp = 0.5 * (1 + torch.erf(p / 2 ** 0.5)) + p * torch.exp(-0.5 * p * p) / (2 * torch.pi) ** 0.5
+    ref = d0.float().cpu().double() * gp
+    assert _rel(d1.float().cpu(), ref.float()) < 1e-2

@@ -480,12 +480,23 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_fast_kernel(ConvGeom g, cons
 // 128-byte row segments (the accumulator layout alone gives 32-byte pieces of 16 different rows).
 // `stage_buf` is this wave's private 8 KB region; the caller has made sure nobody still reads it.
 //
-// TAIL: the output is the gradient of a residual block's output out = relu(bn(y) + shortcut), complete once this
-// tile has been added (beta) or written.  The epilogue then also applies that block's recorded ReLU decisions
-// (tail_bits [row][Co/8], one byte per 8 channels), stores the masked gradient dz, and writes the slab sums the
-// BatchNorm backward needs, bn_partial[slab][0][c] = sum dz, [slab][1][c] = sum dz * y (y = tail_y, the
-// BatchNorm's input, same [row][Co] layout as the output; requires ldc == Co, Co % 8 == 0).
-template <int MODE, int WI, bool TAIL = false>
+// EPI selects what else the epilogue does with a side tensor `tail_y` of the output's own [row][Co] layout
+// (requires ldc == Co, Co % 8 == 0):
+// EPI_BN_TAIL: the output is the gradient of a residual block's output out = relu(bn(y) + shortcut), complete once
+//   this tile has been added (beta) or written.  The epilogue also applies that block's recorded ReLU decisions
+//   (tail_bits [row][Co/8], one byte per 8 channels), stores the masked gradient dz, and writes the slab sums the
+//   BatchNorm backward needs, bn_partial[slab][0][c] = sum dz, [slab][1][c] = sum dz * y (y = tail_y, the
+//   BatchNorm's input).
+// EPI_RESIDUAL: out = result + tail_y (a transformer block's x + f(x), written out of place).
+// EPI_GELU_BWD: out = result * gelu'(tail_y) (the gradient through a GELU whose input tail_y was kept).
+constexpr int EPI_NONE = 0, EPI_BN_TAIL = 1, EPI_RESIDUAL = 2, EPI_GELU_BWD = 3;
+
+__device__ __forceinline__ float gelu_grad_dev(float x) {  // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
+  const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+  return cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+template <int MODE, int WI, int EPI = EPI_NONE>
 __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[WI][4], int m0, int n0, int wm,
                                                 int wn, int lane, const float* __restrict__ bias,
                                                 bf16* __restrict__ out, int relu, int beta, bf16* stage_buf,
@@ -531,7 +542,8 @@ __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[
   // beta: fetch everything the tile accumulates into up front (one memory latency, not one per row group)
   bf16x8 oldv[NIT];
   bf16* orow[NIT];
-  bf16x8 tyv[TAIL ? NIT : 1];
+  constexpr bool TAIL = EPI == EPI_BN_TAIL;
+  bf16x8 tyv[EPI != EPI_NONE ? NIT : 1];
   unsigned tbits[TAIL ? NIT : 1];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
@@ -540,13 +552,13 @@ __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[
     orow[it] = live ? out + (size_t)(MODE == 2 ? phase_out_pixel(g, m) : m) * g.ldc + co : nullptr;
     oldv[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
     if (beta && live && vec) oldv[it] = *reinterpret_cast<const bf16x8*>(orow[it]);
-    if (TAIL) {
+    if (EPI != EPI_NONE) {
       tyv[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (live) tyv[it] = *reinterpret_cast<const bf16x8*>(tail_y + (size_t)m * g.Co + co);
+    }
+    if (TAIL) {
       tbits[it] = 0;
-      if (live) {
-        tyv[it] = *reinterpret_cast<const bf16x8*>(tail_y + (size_t)m * g.Co + co);
-        tbits[it] = tail_bits[((size_t)m * g.Co + co) >> 3];
-      }
+      if (live) tbits[it] = tail_bits[((size_t)m * g.Co + co) >> 3];
     }
   }
 #pragma unroll
@@ -574,6 +586,18 @@ __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[
         pq[e] = fmaf(dz, (float)tyv[it][e], pq[e]);
       }
       if (op) *reinterpret_cast<bf16x8*>(op) = v;
+    } else if (EPI == EPI_RESIDUAL || EPI == EPI_GELU_BWD) {  // host guarantees vec
+      if (op) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float t = (float)v[e];
+          if (beta) t += (float)oldv[it][e];
+          if (EPI == EPI_RESIDUAL) t += (float)tyv[it][e];
+          else t *= gelu_grad_dev((float)tyv[it][e]);
+          v[e] = (bf16)t;
+        }
+        *reinterpret_cast<bf16x8*>(op) = v;
+      }
     } else if (op) {
       if (vec) {
         if (beta) {
@@ -627,7 +651,7 @@ __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[
 // pipeline runs straight through the tile boundaries, so the first k-tile of the next output tile is already
 // streaming in while the epilogue of the current one is written.  Layers with a short reduction (1x1
 // convolutions with 64..256 channels are 1..4 k-tiles deep) otherwise pay a full memory latency per block.
-template <int MODE, int TN_, bool TAIL = false>
+template <int MODE, int TN_, int EPI = EPI_NONE>
 __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, const bf16* __restrict__ src,
                                                                    const bf16* __restrict__ wgt,
                                                                    const float* __restrict__ bias,
@@ -764,7 +788,7 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
       } else {
         // the buffer that was just multiplied is free once every wave has finished reading it
         __syncthreads();
-        nt_epilogue_lds<MODE, WI, TAIL>(g, acc, tile_m * BM, tile_n * TN_, wm, wn, lane, bias,
+        nt_epilogue_lds<MODE, WI, EPI>(g, acc, tile_m * BM, tile_n * TN_, wm, wn, lane, bias,
                                         reinterpret_cast<bf16*>(out), relu, beta, cbuf + wave * (64 * WI * 16),
                                         bn_partial, tail_y, tail_bits);
       }
@@ -1586,10 +1610,55 @@ int vc_conv_dgrad_bn_tail(const int* desc, int dtype, const void* dy, const void
                  "vc_conv_dgrad_bn_tail: unsupported geometry (ask vc_conv_dgrad_bn_tail_supported)");
   const int tiles = ceil_div(g.M, BM) * ceil_div(g.Co, BN);
   const int grid = tiles < nt_persist_blocks() ? tiles : nt_persist_blocks();
-  hipLaunchKernelGGL((igemm_nt_persist_kernel<1, 128, true>), dim3(grid), dim3(NTHR), 0, stream, g, (const bf16*)dy,
+  hipLaunchKernelGGL((igemm_nt_persist_kernel<1, 128, EPI_BN_TAIL>), dim3(grid), dim3(NTHR), 0, stream, g, (const bf16*)dy,
                      (const bf16*)w_packed_t, (const float*)nullptr, dx, 0, 0, beta, tiles, bn_partial,
                      (const bf16*)tail_y, tail_bits);
   VC_LAUNCH_CHECK("vc_conv_dgrad_bn_tail");
+  return VC_OK;
+}
+
+// Geometries whose epilogue can take a side tensor of the output's layout (EPI_RESIDUAL / EPI_GELU_BWD)
+int vc_conv_epilogue_side_supported(const int* desc, int dtype, int mode) {
+  ConvGeom g;
+  if (fill_geom(g, desc, mode ? 1 : 0, "vc_conv_epilogue_side_supported")) return 0;
+  return dgrad_tail_eligible(g, dtype) ? 1 : 0;
+}
+
+// y = conv(x, w) + bias + residual, residual and y of the same [M][co] layout, written out of place (bf16).
+// Replaces the x + f(x) of the Swin blocks (timm SwinTransformerBlock behind model_components.py:254, 412).
+int vc_conv_fwd_residual(const int* desc, int dtype, const void* x, const void* w_packed, const float* bias,
+                         const void* residual, void* y, hipStream_t stream) {
+  ConvGeom g;
+  int rc = fill_geom(g, desc, 0, "vc_conv_fwd_residual");
+  if (rc) return rc;
+  VC_CHECK_ARG(x && w_packed && residual && y, "vc_conv_fwd_residual: null pointer");
+  VC_CHECK_SHAPE(dgrad_tail_eligible(g, dtype),
+                 "vc_conv_fwd_residual: unsupported geometry (ask vc_conv_epilogue_side_supported)");
+  const int tiles = ceil_div(g.M, BM) * ceil_div(g.Co, BN);
+  const int grid = tiles < nt_persist_blocks() ? tiles : nt_persist_blocks();
+  hipLaunchKernelGGL((igemm_nt_persist_kernel<0, 128, EPI_RESIDUAL>), dim3(grid), dim3(NTHR), 0, stream, g,
+                     (const bf16*)x, (const bf16*)w_packed, bias, y, 0, 0, 0, tiles, (float*)nullptr,
+                     (const bf16*)residual, (const uint8_t*)nullptr);
+  VC_LAUNCH_CHECK("vc_conv_fwd_residual");
+  return VC_OK;
+}
+
+// dx = (data gradient of conv) * gelu'(pre), pre = the GELU's input of dx's own layout (bf16): the gradient of
+// gelu(fc1(x)) w.r.t. fc1's output, straight from the data-gradient GEMM of the layer that follows the GELU.
+int vc_conv_dgrad_gelu(const int* desc, int dtype, const void* dy, const void* w_packed_t, const void* pre, void* dx,
+                       hipStream_t stream) {
+  ConvGeom g;
+  int rc = fill_geom(g, desc, 1, "vc_conv_dgrad_gelu");
+  if (rc) return rc;
+  VC_CHECK_ARG(dy && w_packed_t && pre && dx, "vc_conv_dgrad_gelu: null pointer");
+  VC_CHECK_SHAPE(dgrad_tail_eligible(g, dtype),
+                 "vc_conv_dgrad_gelu: unsupported geometry (ask vc_conv_epilogue_side_supported)");
+  const int tiles = ceil_div(g.M, BM) * ceil_div(g.Co, BN);
+  const int grid = tiles < nt_persist_blocks() ? tiles : nt_persist_blocks();
+  hipLaunchKernelGGL((igemm_nt_persist_kernel<1, 128, EPI_GELU_BWD>), dim3(grid), dim3(NTHR), 0, stream, g,
+                     (const bf16*)dy, (const bf16*)w_packed_t, (const float*)nullptr, dx, 0, 0, 0, tiles,
+                     (float*)nullptr, (const bf16*)pre, (const uint8_t*)nullptr);
+  VC_LAUNCH_CHECK("vc_conv_dgrad_gelu");
   return VC_OK;
 }
 

@@ -179,10 +179,17 @@ class _Conv(torch.autograd.Function):
     """y = conv(x, weight) + bias (optionally ReLU) on channels-last tensors."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, kernel, stride, padding, relu, out_f32, ci, join, stats_groups):
+    def forward(ctx, x, weight, bias, kernel, stride, padding, relu, out_f32, ci, join, stats_groups, residual=None,
+                pre_gelu=False):
         _require_cuda(x, "conv")
         ctx.join = join
         x = x.contiguous()
+        # pre_gelu: the layer's input is gelu(x); x itself (the GELU's input) is what autograd differentiates, so
+        # that the data-gradient GEMM can apply gelu' in its epilogue instead of a separate pass
+        ctx.pre = None
+        if pre_gelu:
+            ctx.pre = x
+            x = elementwise(3, x)
         dtype = x.dtype
         N, D, H, W, cip = x.shape
         co = weight.shape[0]
@@ -229,10 +236,20 @@ class _Conv(torch.autograd.Function):
             _timed("conv_fwd", flops, lambda: L.call(
                 "vc_conv_fwd_stats", L.int_array(desc), L.dtype_code(dtype), L.ptr(x), 0, L.ptr(wf), L.ptr(b),
                 L.ptr(y), 0, int(relu), L.ptr(partial), L.stream()), nbytes)
+        elif (residual is not None and FUSE_EPILOGUE_SIDE and not f32 and not relu and
+              tuple(residual.shape) == tuple(y.shape) and residual.dtype == y.dtype and
+              L.query("vc_conv_epilogue_side_supported", L.int_array(desc), L.dtype_code(dtype), 0) == 1):
+            res = residual.contiguous()
+            _timed("conv_fwd", flops, lambda: L.call(
+                "vc_conv_fwd_residual", L.int_array(desc), L.dtype_code(dtype), L.ptr(x), L.ptr(wf), L.ptr(b),
+                L.ptr(res), L.ptr(y), L.stream()), nbytes + float(res.numel() * res.element_size()))
+            residual = None  # added
         else:
             _timed("conv_fwd", flops, lambda: L.call(
                 "vc_conv_fwd", L.int_array(desc), L.dtype_code(dtype), L.ptr(x), 0, L.ptr(wf), L.ptr(b), L.ptr(y), 0,
                 int(relu), int(f32), 0, L.stream()), nbytes)
+        if residual is not None:  # geometry or dtype outside the fused epilogue: a separate add pass
+            y = elementwise(0, y, cast(residual.contiguous().view(y.shape), y.dtype))
         ctx.flops = flops
         ctx.desc, ctx.taps, ctx.relu, ctx.has_bias = desc, taps, relu, bias is not None
         ctx.dims = (co, ci, cip, cop)
@@ -299,7 +316,14 @@ class _Conv(torch.autograd.Function):
             acc = join is not None and join.buf is not None
             dx = join.buf if acc else torch.empty_like(x)
             tail = join.tail if (join is not None and join.pending == 1 and FUSE_BN_TAIL) else None
-            if (tail is not None and tail.bits is not None and tuple(tail.y.shape) == tuple(dx.shape) and
+            gelu_done = False
+            if (ctx.pre is not None and not acc and FUSE_EPILOGUE_SIDE and
+                    L.query("vc_conv_epilogue_side_supported", desc, code, 1) == 1):
+                # dx is the gradient of the GELU's input: gelu' is applied in the GEMM's epilogue
+                _timed("conv_dgrad", ctx.flops, lambda: L.call(
+                    "vc_conv_dgrad_gelu", desc, code, L.ptr(dy), L.ptr(wt), L.ptr(ctx.pre), L.ptr(dx), L.stream()))
+                gelu_done = True
+            elif (tail is not None and tail.bits is not None and tuple(tail.y.shape) == tuple(dx.shape) and
                     L.query("vc_conv_dgrad_bn_tail_supported", desc, code) == 1):
                 # x is the output of a residual block and this is the last contribution to its gradient: the
                 # epilogue applies that block's ReLU decisions and writes the slab sums its BatchNorm backward needs
@@ -313,12 +337,16 @@ class _Conv(torch.autograd.Function):
                 _timed("conv_dgrad", ctx.flops, lambda: L.call(
                     "vc_conv_dgrad", desc, code, L.ptr(dy), 0, L.ptr(wt), L.ptr(dx), 0, int(dtype == torch.float32),
                     int(acc), L.stream()))
+            if ctx.pre is not None and not gelu_done:  # unfused: the gradient w.r.t. gelu(x) times gelu'(x)
+                dx = elementwise(4, dx, ctx.pre)
             if join is not None:
                 dx = join.arrive(dx)
         if side is not None:
             main.wait_stream(side)
         _ready(weight, bias)
-        return dx, None, None, None, None, None, None, None, None, None, None
+        dres = dy if (len(ctx.needs_input_grad) > 11 and ctx.needs_input_grad[11]) else None
+        grads = (dx, None, None, None, None, None, None, None, None, None, None, dres, None)
+        return grads[:len(ctx.needs_input_grad)]
 
 
 # VC_WGRAD_STREAM=1 runs a layer's weight gradient on a side stream beside its data gradient.  Measured on the
@@ -335,6 +363,8 @@ def _side_stream(device):
     return _side_streams[key]
 
 
+# VC_FUSE_EPILOGUE=0 keeps residual adds and the GELU gradient in their own elementwise passes (A/B measurements)
+FUSE_EPILOGUE_SIDE = os.environ.get("VC_FUSE_EPILOGUE", "1") != "0"
 # VC_FUSE_BN_STATS=0 keeps BatchNorm statistics in their own pass over y (A/B measurements)
 FUSE_BN_STATS = os.environ.get("VC_FUSE_BN_STATS", "1") != "0"
 
@@ -499,10 +529,16 @@ def conv_bn(x, weight, bn, groups, bias=None, kernel=1, stride=1, padding=0, rel
                       partial=partial if partial.numel() else None, grad_inplace=grad_inplace)
 
 
-def linear(x, weight, bias=None, relu=False, out_f32=False):
-    """x: [M, C] -> [M, pad8(Co)]."""
+def linear(x, weight, bias=None, relu=False, out_f32=False, residual=None, pre_gelu=False):
+    """x: [M, C] -> [M, pad8(Co)].  residual: [M, pad8(Co)] added to the result (in the GEMM's epilogue where the
+    geometry allows).  pre_gelu: the layer is applied to gelu(x); the gradient through the GELU is then taken in the
+    data-gradient GEMM's epilogue."""
     M, C = x.shape
-    y = conv(x.view(M, 1, 1, 1, C), weight, bias, 1, 1, 0, relu, out_f32)
+    if residual is None and not pre_gelu:
+        y = conv(x.view(M, 1, 1, 1, C), weight, bias, 1, 1, 0, relu, out_f32)
+    else:
+        res = residual.view(M, 1, 1, 1, residual.shape[-1]) if residual is not None else None
+        y = _Conv.apply(x.view(M, 1, 1, 1, C), weight, bias, 1, 1, 0, relu, out_f32, None, None, 0, res, pre_gelu)[0]
     return y.view(M, y.shape[-1])
 
 

@@ -52,12 +52,20 @@ class SwinBlock(nn.Module):
         qkv = ops.linear(y, self.attn.qkv.weight, self.attn.qkv.bias)
         a = ops.window_attention(qkv, self.attn.relative_position_bias_table, F_, H, W, self.attn.heads, self.ws,
                                  self.shift)
-        a = ops.linear(a, self.attn.proj.weight, self.attn.proj.bias)
-        t = ops.add(t, ops.drop_path(a, drop_path, training, F_))
+        dropping = training and drop_path > 0.0
+        if dropping:  # a stochastic-depth branch is scaled per sample before it joins the residual stream
+            a = ops.linear(a, self.attn.proj.weight, self.attn.proj.bias)
+            t = ops.add(t, ops.drop_path(a, drop_path, training, F_))
+        else:         # x + proj(attn) in the projection GEMM's epilogue
+            t = ops.linear(a, self.attn.proj.weight, self.attn.proj.bias, residual=t)
         y = ops.layer_norm(t, self.norm2)
-        y = ops.gelu(ops.linear(y, self.mlp.fc1.weight, self.mlp.fc1.bias))
-        y = ops.linear(y, self.mlp.fc2.weight, self.mlp.fc2.bias)
-        t = ops.add(t, ops.drop_path(y, drop_path, training, F_))
+        h = ops.linear(y, self.mlp.fc1.weight, self.mlp.fc1.bias)
+        # fc2 is applied to gelu(h); the gradient through the GELU is taken in fc2's data-gradient GEMM
+        if dropping:
+            y = ops.linear(h, self.mlp.fc2.weight, self.mlp.fc2.bias, pre_gelu=True)
+            t = ops.add(t, ops.drop_path(y, drop_path, training, F_))
+        else:
+            t = ops.linear(h, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=t, pre_gelu=True)
         return t.view(F_, H, W, C)
 
 
