@@ -128,6 +128,8 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--bucket-mb", type=int, default=32)
+    ap.add_argument("--infer", action="store_true",
+                    help="time the eval-mode forward (predict.py / save_predictions callers) instead of a training step")
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 8 if args.model in ("swinrnn", "clusterswin") else 32
@@ -163,6 +165,36 @@ def main():
     B = args.batch
     x = torch.randn(*shape, generator=g).to(dev)
     y = torch.randint(0, 101, (B, 1), generator=g).to(dev)
+    if args.infer:
+        # forward only, eval-mode BatchNorm, replayed as one hipGraph; every rank runs its own replica
+        from video_classification_amd.graph import GraphedInference
+        infer = GraphedInference(model, x)
+        for _ in range(args.warmup):
+            infer(x)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            infer(x)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = t.item()
+        if rank == 0:
+            print(json.dumps({"metric": "inference clips/sec (16x224^2 UCF101 shape)", "value": world * B * args.steps / el,
+                              "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                              "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                              "config": {"workload": workload.replace("training step", "eval-mode forward"),
+                                         "global_batch": world * B, "launch": "hipgraph"}}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     model.train()
 
     def eager_step():

@@ -357,3 +357,48 @@ def test_graphed_train_step_matches_eager(cuda):
     assert max(abs(a - b) for a, b in zip(le, lg)) < 1e-4
     for k in se:
         assert (se[k].double() - sg[k].double()).abs().max().item() < 1e-5, k
+
+
+def test_inference_callers(cuda, tmp_path):
+    """save_predictions / predict_topk / GraphedInference (the reference's training_utils.py:245-281 and
+    predict.py:134-142) on the tiny CRNN in fp32: predictions equal the CPU oracle's eval-mode arg-max, the pickle
+    holds the reference's DataFrame columns, top-k probabilities match a softmax of the oracle's logits, and the
+    replayed graph returns the eager logits."""
+    import pickle
+    from oracle import torch_oracle as O
+    from video_classification_amd import trainer as TR
+    from video_classification_amd.graph import GraphedInference
+    from video_classification_amd.modules import CRNNModel
+    d = G.load("crnn_tiny_step")
+    ref = O.CRNNModel(G.tiny_crnn_config())
+    ref.load_state_dict(G.group(d, "p"), strict=True)
+    ref.eval()
+    model = CRNNModel(G.tiny_crnn_config())
+    model.load_state_dict(G.group(d, "p"), strict=True)
+    model.to(cuda).set_compute_dtype(torch.float32)
+    x, y = torch.from_numpy(d["in/x"]), torch.from_numpy(d["in/y"])
+    with torch.no_grad():
+        logits_r = ref(x)
+    loader = [(x[:2], y[:2]), (x[2:], y[2:])]
+    path = tmp_path / "out" / "predictions.pkl"
+    df = TR.save_predictions(model, loader, cuda, str(path))
+    assert list(df.columns) == ["y", "y_pred"]
+    assert df["y"].tolist() == y.flatten().tolist()
+    assert df["y_pred"].tolist() == logits_r.argmax(1).tolist()
+    with open(path, "rb") as f:
+        assert pickle.load(f).equals(df)
+    p, idx = TR.predict_topk(model, x[:1].to(cuda), k=5)
+    pr = torch.softmax(logits_r[:1], dim=1)[0]
+    assert idx.tolist() == torch.sort(pr, descending=True, stable=True).indices[:5].tolist()
+    assert G.max_rel(p, pr[idx]) < 1e-4
+    infer = GraphedInference(model, x.to(cuda))
+    out_g = infer(x.to(cuda)).float().cpu()
+    assert G.max_rel(out_g, logits_r) < 2e-4
+    x2 = x.flip(0).contiguous()
+    assert G.max_rel(infer(x2.to(cuda)).float().cpu(), logits_r.flip(0)) < 2e-4
+    # per-script checkpoint layouts (encoder / decoder halves)
+    m2 = CRNNModel(G.tiny_crnn_config())
+    assert TR.load_split_checkpoint({"cnn_encoder_state_dict": {"module." + k: v for k, v in model.encoder.state_dict().items()},
+                                     "rnn_decoder_state_dict": model.decoder.state_dict()}, m2.encoder, m2.decoder)
+    assert all(torch.equal(a.cpu(), b.cpu()) for a, b in zip(m2.state_dict().values(), model.state_dict().values()))
+    assert not TR.load_split_checkpoint({"model_state_dict": {}}, m2.encoder, m2.decoder)

@@ -72,3 +72,30 @@ class GraphedTrainStep:
             self.opt.launch()
         self.opt.after_step()
         return self.loss
+
+
+class GraphedInference:
+    """Eval-mode forward of a model replayed as one hipGraph: logits = infer(x) for clips of the captured shape
+    (predict.py / save_predictions style callers with fixed-size batches).  The returned tensor is the graph's
+    static output buffer: copy it if it must survive the next call."""
+
+    def __init__(self, model, x_example, warmup=2):
+        self.model = model
+        model.eval()
+        self.x = x_example.clone()
+        with torch.no_grad():
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(max(1, warmup)):  # weight packs and scratch buffers are created here, outside capture
+                    model(self.x)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = model(self.x)
+
+    def __call__(self, x):
+        self.x.copy_(x, non_blocking=True)
+        self.graph.replay()
+        return self.out

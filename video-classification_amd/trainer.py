@@ -404,3 +404,58 @@ def load_checkpoint(model, optimizer, checkpoint_path):
         optimizer.load_state_dict(ckpt["optimizer_state_dict"])
     ops.bump_weights_epoch()
     return ckpt["epoch"] + 1
+
+
+# --------------------------------------------------------------------------------------
+# inference callers (forward only, eval-mode BatchNorm)
+# --------------------------------------------------------------------------------------
+def load_split_checkpoint(ckpt, encoder, decoder):
+    """The per-script checkpoint layouts of the reference (predict.py:108-123; SwinCRNN.py:329-336;
+    clusterSwin_TCGlstm.py:345-352): {cnn|swin|cluster_swin}_encoder_state_dict + {rnn|tcglstm}_decoder_state_dict.
+    Returns True if `ckpt` had one of those layouts and both halves were loaded."""
+    for ek, dk in (("cnn_encoder_state_dict", "rnn_decoder_state_dict"),
+                   ("swin_encoder_state_dict", "rnn_decoder_state_dict"),
+                   ("cluster_swin_encoder_state_dict", "tcglstm_decoder_state_dict")):
+        if isinstance(ckpt, dict) and ek in ckpt and dk in ckpt:
+            encoder.load_state_dict(strip_module_prefix(ckpt[ek]))
+            decoder.load_state_dict(strip_module_prefix(ckpt[dk]))
+            ops.bump_weights_epoch()
+            return True
+    return False
+
+
+def predict_topk(model, clip, k=5):
+    """Top-k class probabilities of ONE clip [1,T,3,H,W] (or [1,1,T,H,W] for Conv3D), as predict.py:134-142:
+    eval mode, softmax over the logits, classes by descending probability.  Returns (probs[k], indices[k])."""
+    model.eval()
+    with torch.no_grad():
+        logits = model(clip)
+        probs = torch.softmax(logits.float(), dim=1)[0]
+    k = min(k, probs.numel())
+    p, idx = torch.sort(probs, descending=True, stable=True)
+    return p[:k].cpu(), idx[:k].cpu()
+
+
+def save_predictions(model, test_loader, device, save_path, action_names=None):
+    """The reference's save_predictions (training_utils.py:245-281): eval-mode arg-max over a loader, written as
+    a pickled DataFrame {'y', 'y_pred'} and returned.  Predictions stay on the device until the loader is
+    exhausted (one read-back instead of two per batch)."""
+    import pickle
+
+    import pandas as pd
+    model.eval()
+    preds, labels = [], []
+    with torch.no_grad():
+        for data, target in test_loader:
+            data = data.to(device, non_blocking=True)
+            output = model(data)
+            preds.append(output.argmax(dim=1))
+            labels.append(target.reshape(-1))
+    y_pred = torch.cat(preds).cpu().numpy().flatten() if preds else []
+    y = torch.cat(labels).cpu().numpy().flatten() if labels else []
+    results_df = pd.DataFrame({"y": y, "y_pred": y_pred})
+    if not (dist.is_initialized() and dist.get_rank() != 0):
+        os.makedirs(os.path.dirname(save_path) or ".", exist_ok=True)
+        with open(save_path, "wb") as f:
+            pickle.dump(results_df, f)
+    return results_df
