@@ -221,21 +221,24 @@ __device__ __forceinline__ void nt_epilogue(const ConvGeom& g, f32x4 (&acc)[WI][
 // GLDS = true : tiles are staged global -> LDS by LDS-DMA (no VGPR round trip, no ds_write); the XOR
 //               swizzle of the LDS image is applied to each lane's SOURCE address.
 // GLDS = false: register-staged variant (global_load -> VGPR -> ds_write), kept for A/B measurements.
-template <int MODE, bool GLDS>
+// TN_ = 128, or 64 for layers with at most 64 output channels (first layers: 3 -> 32 / 64, 1 -> 32; 32 -> 64).
+template <int MODE, bool GLDS, int TN_ = 128>
 __global__ __launch_bounds__(NTHR, 2) void igemm_nt_bf16_kernel(ConvGeom g, const bf16* __restrict__ src,
                                                                 const bf16* __restrict__ wgt,
                                                                 const float* __restrict__ bias, void* __restrict__ out,
                                                                 int relu, int out_f32, int beta) {
-  __shared__ __attribute__((aligned(1024))) bf16 smem[2 * (BM + BN) * BK];
+  __shared__ __attribute__((aligned(1024))) bf16 smem[2 * (BM + TN_) * BK];
+  constexpr int WI = TN_ / 32;     // 16-channel tiles per wave
+  constexpr int NWROW = TN_ / 32;  // weight rows staged per thread
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int tiles_n = (g.Co + BN - 1) / BN;
+  const int tiles_n = (g.Co + TN_ - 1) / TN_;
   int logical;
   xcd_remap(logical);
   const int tile_m = logical / tiles_n, tile_n = logical - tile_m * tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int m0 = tile_m * BM, n0 = tile_n * TN_;
 
   // staging role of this thread: LDS row lrow (+32*i), physical 16-byte slot pchunk of the row,
   // which holds logical k-chunk lchunk (same XOR for the four rows: 32*i does not change (row>>1)&7)
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_bf16_kernel(ConvGeom g, cons
   for (int i = 0; i < 4; ++i) rp[i] = decode_row<MODE>(g, m0 + lrow + 32 * i);
 
   const int nk = (g.K + BK - 1) / BK;
-  bf16x8 areg[4], wreg[4];
+  bf16x8 areg[4], wreg[NWROW];
 
   auto stage_dma = [&](int kt, int buf) {
     const int kc = kt * (BK / 8) + lchunk;
@@ -254,18 +257,21 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_bf16_kernel(ConvGeom g, cons
     int rd, rh, rw, c;
     decode_chunk(g, kc, rd, rh, rw, c);
     const int wcol = weight_col<MODE>(g, kc, rd, rh, rw, c);
-    bf16* sA = smem + buf * (BM + BN) * BK;
+    bf16* sA = smem + buf * (BM + TN_) * BK;
     bf16* sW = sA + BM * BK;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const void* asrc = vc_zero_src;
       const int pix = gather_pixel<MODE>(g, rp[i], rd, rh, rw);
       if (kvalid && pix >= 0) asrc = src + (size_t)pix * g.ldi + c;
+      // this wave's instruction fills rows [32*i + 8*wave, +8): 8 rows x 128 B = 64 lanes x 16 B
+      glds16(asrc, sA + (32 * i + 8 * wave) * BK);
+    }
+#pragma unroll
+    for (int i = 0; i < NWROW; ++i) {
       const void* wsrc = vc_zero_src;
       const int co = n0 + lrow + 32 * i;
       if (kvalid && co < g.Co) wsrc = wgt + (size_t)co * g.ldw + wcol;
-      // this wave's instruction fills rows [32*i + 8*wave, +8): 8 rows x 128 B = 64 lanes x 16 B
-      glds16(asrc, sA + (32 * i + 8 * wave) * BK);
       glds16(wsrc, sW + (32 * i + 8 * wave) * BK);
     }
   };
@@ -281,6 +287,9 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_bf16_kernel(ConvGeom g, cons
       const int pix = gather_pixel<MODE>(g, rp[i], rd, rh, rw);
       if (kvalid && pix >= 0) v = *reinterpret_cast<const bf16x8*>(src + (size_t)pix * g.ldi + c);
       areg[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NWROW; ++i) {
       bf16x8 w = {0, 0, 0, 0, 0, 0, 0, 0};
       const int co = n0 + lrow + 32 * i;
       if (kvalid && co < g.Co) w = *reinterpret_cast<const bf16x8*>(wgt + (size_t)co * g.ldw + wcol);
@@ -288,19 +297,17 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_bf16_kernel(ConvGeom g, cons
     }
   };
   auto store_tile = [&](int buf) {
-    bf16* sA = smem + buf * (BM + BN) * BK;
+    bf16* sA = smem + buf * (BM + TN_) * BK;
     bf16* sW = sA + BM * BK;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = lrow + 32 * i;
-      *reinterpret_cast<bf16x8*>(sA + row * BK + pchunk * 8) = areg[i];
-      *reinterpret_cast<bf16x8*>(sW + row * BK + pchunk * 8) = wreg[i];
-    }
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<bf16x8*>(sA + (lrow + 32 * i) * BK + pchunk * 8) = areg[i];
+#pragma unroll
+    for (int i = 0; i < NWROW; ++i) *reinterpret_cast<bf16x8*>(sW + (lrow + 32 * i) * BK + pchunk * 8) = wreg[i];
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[WI][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < WI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -319,19 +326,20 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_bf16_kernel(ConvGeom g, cons
       if (GLDS) stage_dma(kt + 1, buf ^ 1);
       else load_tile(kt + 1);
     }
-    const bf16* sA = smem + buf * (BM + BN) * BK;
+    const bf16* sA = smem + buf * (BM + TN_) * BK;
     const bf16* sW = sA + BM * BK;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int chunk = ks * 4 + (lane >> 4);
-      bf16x8 wf[4], af[4];
+      bf16x8 wf[WI], af[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        wf[i] = *reinterpret_cast<const bf16x8*>(sW + nt_lds_off(wn * 64 + i * 16 + (lane & 15), chunk));
-        af[i] = *reinterpret_cast<const bf16x8*>(sA + nt_lds_off(wm * 64 + i * 16 + (lane & 15), chunk));
-      }
+      for (int i = 0; i < WI; ++i)
+        wf[i] = *reinterpret_cast<const bf16x8*>(sW + nt_lds_off(wn * (WI * 16) + i * 16 + (lane & 15), chunk));
 #pragma unroll
       for (int i = 0; i < 4; ++i)
+        af[i] = *reinterpret_cast<const bf16x8*>(sA + nt_lds_off(wm * 64 + i * 16 + (lane & 15), chunk));
+#pragma unroll
+      for (int i = 0; i < WI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
@@ -344,7 +352,7 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_bf16_kernel(ConvGeom g, cons
     __syncthreads();
   }
 
-  nt_epilogue<MODE>(g, acc, m0, n0, wm, wn, lane, bias, out, relu, out_f32, beta);
+  nt_epilogue<MODE, WI>(g, acc, m0, n0, wm, wn, lane, bias, out, relu, out_f32, beta);
 }
 
 // NT kernel for source channel counts that are a multiple of BK (every layer past a network's first): a
@@ -1486,6 +1494,9 @@ int launch_nt(const ConvGeom& g, int dtype, const void* src, const void* wgt, co
     } else if (use_glds() && g.Ci % BK == 0 && g.ldi % 8 == 0 && nt_variant() >= 1)
       hipLaunchKernelGGL((igemm_nt_fast_kernel<MODE>), dim3(tiles), dim3(NTHR), 0, stream, g, (const bf16*)src,
                          (const bf16*)wgt, bias, out, relu, out_f32, beta);
+    else if (use_glds() && g.Co <= nt_narrow())  // a 128-wide channel tile would be at least half padding
+      hipLaunchKernelGGL((igemm_nt_bf16_kernel<MODE, true, 64>), dim3(ceil_div(g.M, BM) * ceil_div(g.Co, 64)),
+                         dim3(NTHR), 0, stream, g, (const bf16*)src, (const bf16*)wgt, bias, out, relu, out_f32, beta);
     else if (use_glds())
       hipLaunchKernelGGL((igemm_nt_bf16_kernel<MODE, true>), dim3(tiles), dim3(NTHR), 0, stream, g, (const bf16*)src,
                          (const bf16*)wgt, bias, out, relu, out_f32, beta);
