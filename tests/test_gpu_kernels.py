@@ -103,9 +103,10 @@ def test_maxpool(cuda, dt, k, s, p, H, W):
 
 
 @pytest.mark.parametrize("dt", DTYPES, ids=IDS)
-def test_global_avgpool(cuda, dt):
+@pytest.mark.parametrize("S", [49, 784, 300], ids=["resnet_7x7", "conv3d_16x7x7", "ragged_300"])
+def test_global_avgpool(cuda, dt, S):
     from video_classification_amd import ops
-    x = rnd(dt, 5, 49, 64, seed=9)
+    x = rnd(dt, 5, S, 64, seed=9)
     xr = x.clone().requires_grad_(True)
     yr = xr.mean(1)
     dy = rnd(dt, 5, 64, seed=10)

@@ -207,6 +207,29 @@ __global__ void avgpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, i
   }
 }
 
+// long pooling extents (Conv3D: 16 x 7 x 7 = 784 positions, few samples): one wave per (sample, 8 channels),
+// the positions spread over its lanes, instead of one thread walking all of them
+template <typename T>
+__global__ void avgpool_fwd_wave_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int S, int C8) {
+  const int64_t pair = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (pair >= (int64_t)N * C8) return;
+  const int lane = threadIdx.x & 63;
+  const int cc = (int)(pair % C8);
+  const int n = (int)(pair / C8);
+  F8 acc;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc.v[j] = 0.f;
+  for (int sp = lane; sp < S; sp += 64) {
+    const F8 v = load8(x + (((size_t)n * S + sp) * C8 + cc) * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc.v[j] += v.v[j];
+  }
+  const float inv = 1.f / S;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc.v[j] = wave_sum(acc.v[j]) * inv;
+  if (lane == 0) store8(y + pair * 8, acc);
+}
+
 template <typename T>
 __global__ void avgpool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int S, int C8) {
   const int64_t total = (int64_t)N * S * C8;
@@ -529,9 +552,16 @@ int vc_maxpool2d_bwd(int dtype, const void* dy, const uint8_t* idx, void* dx, in
 int vc_avgpool_fwd(int dtype, const void* x, void* y, int N, int S, int C, hipStream_t stream) {
   VC_CHECK_ARG(x && y, "vc_avgpool_fwd: null pointer");
   VC_CHECK_SHAPE(C % 8 == 0 && N > 0 && S > 0, "vc_avgpool_fwd: bad shape");
-  DISPATCH_T(dtype, "vc_avgpool_fwd",
-             hipLaunchKernelGGL((avgpool_fwd_kernel<T>), dim3(ew_grid((int64_t)N * (C / 8))), dim3(NTHR), 0, stream,
-                                (const T*)x, (T*)y, N, S, C / 8);)
+  if (S >= 256) {
+    const int64_t pairs = (int64_t)N * (C / 8);
+    DISPATCH_T(dtype, "vc_avgpool_fwd",
+               hipLaunchKernelGGL((avgpool_fwd_wave_kernel<T>), dim3((unsigned)ceil_div64(pairs, NTHR / 64)), dim3(NTHR),
+                                  0, stream, (const T*)x, (T*)y, N, S, C / 8);)
+  } else {
+    DISPATCH_T(dtype, "vc_avgpool_fwd",
+               hipLaunchKernelGGL((avgpool_fwd_kernel<T>), dim3(ew_grid((int64_t)N * (C / 8))), dim3(NTHR), 0, stream,
+                                  (const T*)x, (T*)y, N, S, C / 8);)
+  }
   VC_LAUNCH_CHECK("vc_avgpool_fwd");
   return VC_OK;
 }
