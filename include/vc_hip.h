@@ -132,6 +132,17 @@ int vc_bn_bwd_sums_from_partial(const float* partial, const float* mean, const f
 int vc_bn_bwd_apply(int dtype, const void* y, const void* dout, const void* act, const float* mean,
                     const float* invstd, const float* scale, const float* shift, const float* s1, const float* s2,
                     void* dy, void* dres, int G, int rpg, int C, int relu, vc_stream_t stream);
+/* BatchNorm + ReLU + max-pool in one pass each way: torchvision ResNet's bn1 / relu / maxpool(3, 2, 1) behind
+ * model_components.py:164-165, and BatchNorm3d / ReLU / MaxPool3d((1,2,2)) of Conv3D (UCF101_3DCNN_refactored.py:
+ * 67-69, 73-75, 79-81, 85-87).  y is [N frames][H][W][C], a BatchNorm group is npg = N/G consecutive frames; the
+ * full-resolution activation is never written.  vc_bn_pool_fwd writes the pooled tensor and the arg-max taps (one
+ * byte per pooled element); vc_bn_pool_bwd gathers the pooled gradient dyp through them: phase 0 accumulates the
+ * BatchNorm backward reductions into s1 / s2 [G][C] (zeroed by the caller), phase 1 writes dy. */
+int vc_bn_pool_fwd(int dtype, const void* y, const float* scale, const float* shift, void* out, uint8_t* idx, int N,
+                   int H, int W, int C, int k, int s, int p, int npg, vc_stream_t stream);
+int vc_bn_pool_bwd(int dtype, int phase, const void* y, const void* dyp, const uint8_t* idx, const float* mean,
+                   const float* invstd, const float* scale, const float* shift, float* s1, float* s2, void* dy, int N,
+                   int H, int W, int C, int k, int s, int p, int G, vc_stream_t stream);
 /* flags: bit 0 = add to dgamma/dbeta instead of overwriting; bit 1 = zero s1/s2 after reading (dgamma and dbeta may
  * both be NULL: the call then only clears) */
 int vc_bn_bwd_params(float* s1, float* s2, float* dgamma, float* dbeta, int G, int C, int flags,

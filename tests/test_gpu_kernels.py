@@ -85,6 +85,56 @@ def test_batchnorm_groups(cuda, dt, shape, groups, relu, res, inplace):
 
 
 @pytest.mark.parametrize("dt", DTYPES, ids=IDS)
+@pytest.mark.parametrize("k,s,p,N,D,H,W,C,groups", [(3, 2, 1, 6, 1, 14, 14, 64, 3), (3, 2, 1, 4, 1, 9, 11, 24, 2),
+                                                    (2, 2, 0, 2, 4, 8, 6, 32, 1), (2, 2, 0, 2, 3, 7, 7, 16, 1)])
+def test_batchnorm_relu_maxpool_fused(cuda, dt, k, s, p, N, D, H, W, C, groups):
+    """BatchNorm + ReLU + max-pool in one pass each way (vc_bn_pool_fwd / vc_bn_pool_bwd) against the two-pass form
+    of the same library (BatchNorm + ReLU, then max-pool): identical pooled output and running statistics, input
+    and parameter gradients equal up to the order of the reductions; and against plain PyTorch in fp32."""
+    from video_classification_amd import ops
+    x = rnd(dt, N, D, H, W, C, seed=31) * 1.5 + 0.2
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    dy = rnd(dt, N, D, Ho, Wo, C, seed=32)
+    res = {}
+    for mode in (2, 0):  # every geometry fused / never fused
+        ops.FUSE_BN_POOL = mode
+        try:
+            bn = nn.BatchNorm1d(C, momentum=0.01)
+            with torch.no_grad():
+                bn.weight.copy_(torch.rand(C, generator=torch.Generator().manual_seed(33)) + 0.5)
+                bn.bias.copy_(torch.randn(C, generator=torch.Generator().manual_seed(34)) * 0.3)
+            bn.to(cuda)
+            xm = x.to(cuda, dt).requires_grad_(True)
+            out = ops.batch_norm_relu_pool(xm, bn, groups, k, s, p)
+            out.backward(dy.to(cuda, dt))
+            torch.cuda.synchronize()
+            res[mode] = (out.detach().float().cpu(), xm.grad.float().cpu(), bn.weight.grad.cpu(), bn.bias.grad.cpu(),
+                         bn.running_mean.cpu(), bn.running_var.cpu(), int(bn.num_batches_tracked))
+        finally:
+            ops.FUSE_BN_POOL = 1
+    f, u = res[2], res[0]
+    assert torch.equal(f[0], u[0])
+    t = tol(dt)
+    for i in (1, 2, 3):
+        assert G.max_rel(f[i], u[i]) < t, i
+    assert torch.equal(f[4], u[4]) and torch.equal(f[5], u[5]) and f[6] == u[6] == groups
+    if dt == torch.float32:  # plain PyTorch: per-group BatchNorm, ReLU, per-frame max-pool
+        xr = x.clone().requires_grad_(True)
+        bnr = nn.BatchNorm1d(C, momentum=0.01)
+        with torch.no_grad():
+            bnr.weight.copy_(torch.rand(C, generator=torch.Generator().manual_seed(33)) + 0.5)
+            bnr.bias.copy_(torch.randn(C, generator=torch.Generator().manual_seed(34)) * 0.3)
+        fr = xr.view(N * D, H, W, C)
+        npg = N * D // groups
+        a = torch.cat([F.relu(bnr(fr[g * npg:(g + 1) * npg].reshape(-1, C))).view(npg, H, W, C) for g in range(groups)])
+        o = F.max_pool2d(a.permute(0, 3, 1, 2), k, s, p).permute(0, 2, 3, 1).reshape(N, D, Ho, Wo, C)
+        o.backward(dy)
+        assert G.max_rel(f[0], o.detach()) < t
+        assert G.max_rel(f[1], xr.grad) < 2 * t
+        assert G.max_rel(f[2], bnr.weight.grad) < 2 * t and G.max_rel(f[3], bnr.bias.grad) < 2 * t
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=IDS)
 @pytest.mark.parametrize("k,s,p,H,W", [(3, 2, 1, 14, 14), (3, 2, 1, 9, 11), (2, 2, 0, 8, 6), (2, 2, 0, 7, 7)])
 def test_maxpool(cuda, dt, k, s, p, H, W):
     from video_classification_amd import ops

@@ -400,6 +400,180 @@ __global__ __launch_bounds__(NTHR) void bn_bwd_apply_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// BatchNorm + ReLU + max-pool in one pass each way (ResNet stem: 3x3 / 2 / 1; Conv3D: (1,2,2) after every block).
+// The full-resolution activation relu(bn(y)) is never written: forward reads y and writes the pooled tensor and
+// the arg-max taps; backward gathers the pooled gradient through those taps where the unfused path would have
+// read a full-resolution gradient tensor (written once, read twice).
+// Rows are frames n of H x W pixels; a BatchNorm group is `npg` consecutive frames.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void bn_pool_fwd_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                   const float* __restrict__ shift, T* __restrict__ out, uint8_t* __restrict__ idx,
+                                   int N, int H, int W, int C8, int Ho, int Wo, int k, int s, int p, int npg) {
+  const int64_t total = (int64_t)N * Ho * Wo * C8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % C8);
+    int64_t t = i / C8;
+    const int ow = (int)(t % Wo);
+    t /= Wo;
+    const int oh = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    const size_t po = (size_t)(n / npg) * C8 * 8 + cc * 8;
+    const F8 sc = load8(scale + po), sh = load8(shift + po);
+    float best[8];
+    int bi[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      best[j] = -INFINITY;
+      bi[j] = 0;
+    }
+    for (int r = 0; r < k; ++r) {
+      const int ih = oh * s - p + r;
+      if ((unsigned)ih >= (unsigned)H) continue;
+      for (int q = 0; q < k; ++q) {
+        const int iw = ow * s - p + q;
+        if ((unsigned)iw >= (unsigned)W) continue;
+        const F8 v = load8(y + ((((size_t)n * H + ih) * W + iw) * C8 + cc) * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          // rounded to the storage type before the comparison: the same winner as a max-pool over the stored
+          // activation would pick
+          const float a = to_f32(from_f32<T>(fmaxf(fmaf(v.v[j], sc.v[j], sh.v[j]), 0.f)));
+          if (a > best[j]) {
+            best[j] = a;
+            bi[j] = r * k + q;
+          }
+        }
+      }
+    }
+    F8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.v[j] = best[j];
+    store8(out + i * 8, o);
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      lo |= (uint32_t)bi[j] << (8 * j);
+      hi |= (uint32_t)bi[4 + j] << (8 * j);
+    }
+    *reinterpret_cast<uint2*>(idx + i * 8) = make_uint2(lo, hi);
+  }
+}
+
+// gradient that reaches element (n, ih, iw, channels 8cc..8cc+7) of the max-pool's input: the pooled gradients of
+// the windows that contain it and whose recorded tap is this element
+template <typename T>
+__device__ __forceinline__ F8 pool_grad_gather(const T* __restrict__ dyp, const uint8_t* __restrict__ idx, int n,
+                                               int ih, int iw, int cc, int C8, int Ho, int Wo, int k, int s, int p) {
+  F8 acc;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc.v[j] = 0.f;
+  const int oh_lo = max(0, (ih + p - k + s) / s), oh_hi = min(Ho - 1, (ih + p) / s);
+  const int ow_lo = max(0, (iw + p - k + s) / s), ow_hi = min(Wo - 1, (iw + p) / s);
+  for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+    const int r = ih - (oh * s - p);
+    if (r < 0 || r >= k) continue;
+    for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+      const int q = iw - (ow * s - p);
+      if (q < 0 || q >= k) continue;
+      const size_t o = ((((size_t)n * Ho + oh) * Wo + ow) * C8 + cc) * 8;
+      const uint2 w = *reinterpret_cast<const uint2*>(idx + o);
+      const F8 d = load8(dyp + o);
+      const int tap = r * k + q;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int b = (int)(((j < 4 ? w.x : w.y) >> (8 * (j & 3))) & 0xff);
+        if (b == tap) acc.v[j] += d.v[j];
+      }
+    }
+  }
+  return acc;
+}
+
+// MODE 0: s1[g][c] += sum dz, s2[g][c] += sum dz * xhat     (dz = gathered gradient where bn(y) > 0)
+// MODE 1: dy = scale * (dz - s1/cnt - xhat * s2/cnt)
+template <typename T, int MODE>
+__global__ __launch_bounds__(NTHR) void bn_pool_bwd_kernel(
+    const T* __restrict__ y, const T* __restrict__ dyp, const uint8_t* __restrict__ idx,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ scale,
+    const float* __restrict__ shift, float* __restrict__ s1, float* __restrict__ s2, T* __restrict__ dy, int C, int H,
+    int W, int Ho, int Wo, int k, int s, int p, int rpg, int rows_per_block, float inv_cnt) {
+  __shared__ float red[2][NTHR][8];
+  const int C8 = C >> 3, g = blockIdx.y;
+  const RowWalk w = row_walk(C8, rpg, rows_per_block);
+  const int HW = H * W;
+  for (int cc0 = 0; cc0 < C8; cc0 += w.lanesC) {  // uniform trip count (barriers inside for MODE 0)
+    const int cc = cc0 + w.cl;
+    const bool cvalid = cc < C8;
+    float a1[8], a2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a1[i] = a2[i] = 0.f;
+    if (cvalid) {
+      const size_t po = (size_t)g * C + cc * 8;
+      const F8 sc = load8(scale + po), sh = load8(shift + po), mu = load8(mean + po), is = load8(invstd + po);
+      F8 kb, kc;
+      if (MODE == 1) {
+        const F8 t1 = load8(s1 + po), t2 = load8(s2 + po);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float t = sc.v[i] * is.v[i] * t2.v[i] * inv_cnt;
+          kb.v[i] = -t;
+          kc.v[i] = fmaf(t, mu.v[i], -sc.v[i] * t1.v[i] * inv_cnt);
+        }
+      }
+      for (int r = w.r_begin + w.rl; r < w.r_end; r += w.RL) {
+        const int pix = g * rpg + r;
+        const int n = pix / HW, rem = pix - n * HW;
+        const int ih = rem / W, iw = rem - ih * W;
+        const size_t off = (size_t)pix * C + cc * 8;
+        const F8 yv = load8(y + off);
+        F8 dz = pool_grad_gather(dyp, idx, n, ih, iw, cc, C8, Ho, Wo, k, s, p);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dz.v[i] = fmaf(yv.v[i], sc.v[i], sh.v[i]) > 0.f ? dz.v[i] : 0.f;
+        if (MODE == 0) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            a1[i] += dz.v[i];
+            a2[i] = fmaf(dz.v[i], (yv.v[i] - mu.v[i]) * is.v[i], a2[i]);
+          }
+        } else {
+          F8 o;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o.v[i] = fmaf(sc.v[i], dz.v[i], fmaf(kb.v[i], yv.v[i], kc.v[i]));
+          store8(dy + off, o);
+        }
+      }
+    }
+    if (MODE == 0) {
+      const int CB = w.lanesC * 8;
+      float* r1 = &red[0][0][0];
+      float* r2 = r1 + NTHR * 8;
+      if (w.rl < w.RL) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          r1[w.rl * CB + w.cl * 8 + i] = a1[i];
+          r2[w.rl * CB + w.cl * 8 + i] = a2[i];
+        }
+      }
+      __syncthreads();
+      for (int ch = threadIdx.x; ch < CB; ch += NTHR) {
+        const int cg = cc0 * 8 + ch;
+        if (cg < C) {
+          float t1 = 0.f, t2 = 0.f;
+          for (int q = 0; q < w.RL; ++q) {
+            t1 += r1[q * CB + ch];
+            t2 += r2[q * CB + ch];
+          }
+          atomicAdd(s1 + g * C + cg, t1);
+          atomicAdd(s2 + g * C + cg, t2);
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 // dgamma[c] (+)= sum_g s2[g][c]; dbeta[c] (+)= sum_g s1[g][c]
 // flags: bit 0 = add to dgamma/dbeta instead of overwriting, bit 1 = zero s1/s2 after reading them
 __global__ void bn_bwd_params_kernel(float* __restrict__ s1, float* __restrict__ s2, float* __restrict__ dgamma,
@@ -740,6 +914,62 @@ int vc_bn_bwd_apply(int dtype, const void* y, const void* dout, const void* act,
                        inv_cnt, relu);
   else { vc_set_error("vc_bn_bwd_apply: unsupported dtype %d", dtype); return VC_ERR_DTYPE; }
   VC_LAUNCH_CHECK("vc_bn_bwd_apply");
+  return VC_OK;
+}
+
+// relu(y * scale[g] + shift[g]) max-pooled k x k / s / p per frame, in one pass: y [N][H][W][C] (N frames, groups of
+// npg consecutive frames) -> out [N][Ho][Wo][C] and the arg-max taps idx (one byte per output element).
+int vc_bn_pool_fwd(int dtype, const void* y, const float* scale, const float* shift, void* out, uint8_t* idx, int N,
+                   int H, int W, int C, int k, int s, int p, int npg, hipStream_t stream) {
+  VC_CHECK_ARG(y && scale && shift && out && idx, "vc_bn_pool_fwd: null pointer");
+  VC_CHECK_SHAPE(C % 8 == 0 && N > 0 && H > 0 && W > 0 && k > 0 && k <= 15 && s > 0 && p >= 0 && p < k && npg > 0,
+                 "vc_bn_pool_fwd: bad shape");
+  const int Ho = (H + 2 * p - k) / s + 1, Wo = (W + 2 * p - k) / s + 1;
+  VC_CHECK_SHAPE(Ho > 0 && Wo > 0, "vc_bn_pool_fwd: empty output");
+  const int64_t total = (int64_t)N * Ho * Wo * (C / 8);
+  const unsigned grid = (unsigned)(ceil_div64(total, NTHR) < 65536 * 16 ? ceil_div64(total, NTHR) : 65536 * 16);
+  if (dtype == VC_BF16)
+    hipLaunchKernelGGL((bn_pool_fwd_kernel<bf16>), dim3(grid), dim3(NTHR), 0, stream, (const bf16*)y, scale, shift,
+                       (bf16*)out, idx, N, H, W, C / 8, Ho, Wo, k, s, p, npg);
+  else if (dtype == VC_F32)
+    hipLaunchKernelGGL((bn_pool_fwd_kernel<float>), dim3(grid), dim3(NTHR), 0, stream, (const float*)y, scale, shift,
+                       (float*)out, idx, N, H, W, C / 8, Ho, Wo, k, s, p, npg);
+  else { vc_set_error("vc_bn_pool_fwd: unsupported dtype %d", dtype); return VC_ERR_DTYPE; }
+  VC_LAUNCH_CHECK("vc_bn_pool_fwd");
+  return VC_OK;
+}
+
+// Backward of vc_bn_pool_fwd.  phase 0: s1 / s2 [G][C] (zeroed by the caller) += the BatchNorm backward reductions of
+// dz = (pooled gradient dyp gathered through idx) * (bn(y) > 0); phase 1: dy = the gradient of the BatchNorm's input.
+int vc_bn_pool_bwd(int dtype, int phase, const void* y, const void* dyp, const uint8_t* idx, const float* mean,
+                   const float* invstd, const float* scale, const float* shift, float* s1, float* s2, void* dy, int N,
+                   int H, int W, int C, int k, int s, int p, int G, hipStream_t stream) {
+  VC_CHECK_ARG(y && dyp && idx && mean && invstd && scale && shift && s1 && s2 && (phase == 0 || dy),
+               "vc_bn_pool_bwd: null pointer");
+  VC_CHECK_SHAPE(C % 8 == 0 && N > 0 && G > 0 && G < 65536 && N % G == 0 && k > 0 && s > 0 && p >= 0 && p < k,
+                 "vc_bn_pool_bwd: bad shape");
+  const int Ho = (H + 2 * p - k) / s + 1, Wo = (W + 2 * p - k) / s + 1;
+  const int rpg = N / G * H * W;
+  const float inv_cnt = 1.f / (float)rpg;
+  const int C8 = C / 8, lanesC = C8 < NTHR ? C8 : NTHR, RL = NTHR / lanesC;
+  int rows = 16 * RL;
+  if (phase == 0) {
+    while (rows < rpg && (int64_t)ceil_div(rpg, rows) * G > bn_reduce_blocks()) rows *= 2;
+  } else {
+    rows = 4 * RL;
+    while (rows < 32 * RL && (int64_t)ceil_div(rpg, rows * 2) * G >= 4096) rows *= 2;
+  }
+  const dim3 grid(ceil_div(rpg, rows), G);
+#define VC_BN_POOL_BWD(T, MODE)                                                                                        \
+  hipLaunchKernelGGL((bn_pool_bwd_kernel<T, MODE>), grid, dim3(NTHR), 0, stream, (const T*)y, (const T*)dyp, idx, mean, \
+                     invstd, scale, shift, s1, s2, (T*)dy, C, H, W, Ho, Wo, k, s, p, rpg, rows, inv_cnt)
+  if (dtype == VC_BF16) {
+    if (phase == 0) VC_BN_POOL_BWD(bf16, 0); else VC_BN_POOL_BWD(bf16, 1);
+  } else if (dtype == VC_F32) {
+    if (phase == 0) VC_BN_POOL_BWD(float, 0); else VC_BN_POOL_BWD(float, 1);
+  } else { vc_set_error("vc_bn_pool_bwd: unsupported dtype %d", dtype); return VC_ERR_DTYPE; }
+#undef VC_BN_POOL_BWD
+  VC_LAUNCH_CHECK("vc_bn_pool_bwd");
   return VC_OK;
 }
 

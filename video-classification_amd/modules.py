@@ -161,11 +161,9 @@ def make_resnet_trunk(arch="resnet152"):
 
 def run_resnet_trunk(trunk, x_3d, T, dtype):
     """x_3d: raw fp32 clip [B,T,3,H,W] -> pooled features [T*B, 2048] (frames time-major)."""
+    # conv1 -> bn1 -> relu -> maxpool(3, 2, 1): the last three are one pass (the 112 x 112 activation is never written)
     a = ops.input_conv(x_3d, trunk[0].weight, None, (1, 7, 7), (1, 2, 2), (0, 3, 3), "clip", dtype, bn=trunk[1],
-                       groups=T, relu=True)
-    F_, _, H, W, C = a.shape
-    a = ops.max_pool2d(a.view(F_, H, W, C), 3, 2, 1)
-    a = a.view(F_, 1, a.shape[1], a.shape[2], C)
+                       groups=T, relu=True, pool=(3, 2, 1))
     for li in range(4, 8):
         for blk in trunk[li]:
             a = blk.run(a, T)
@@ -272,14 +270,12 @@ class Conv3DModel(_HipModule):
         a = None
         for i in range(4):
             cv, bn = self.conv3d[4 * i], self.conv3d[4 * i + 1]
+            # BatchNorm3d + ReLU + MaxPool3d((1,2,2)) as one pass: the pool never crosses the depth axis
             if i == 0:  # 1-channel layer straight from the fp32 volume (W taps folded into the channel axis)
                 a = ops.input_conv(x, cv.weight, cv.bias, 3, 1, 1, "volume", self.compute_dtype, bn=bn, groups=1,
-                                   relu=True)
+                                   relu=True, pool=(2, 2, 0))
             else:
-                a = ops.conv_bn(a, cv.weight, bn, 1, cv.bias, 3, 1, 1, relu=True)
-            B, D, H, W, C = a.shape
-            a = ops.max_pool2d(a.view(B * D, H, W, C), 2, 2, 0)     # MaxPool3d((1,2,2))
-            a = a.view(B, D, H // 2, W // 2, C)
+                a = ops.conv_bn(a, cv.weight, bn, 1, cv.bias, 3, 1, 1, relu=True, pool=(2, 2, 0))
         B, D, H, W, C = a.shape
         f = ops.global_avg_pool(a.view(B, D * H * W, C))
         f = ops.dropout(f, self.dropout_p, self.training)

@@ -467,13 +467,15 @@ class _InputConv(torch.autograd.Function):
         return None, None, None, None, None, None, None, None, None
 
 
-def input_conv(x, weight, bias, kernel, stride, padding, layout, dtype, bn=None, groups=1, relu=False):
+def input_conv(x, weight, bias, kernel, stride, padding, layout, dtype, bn=None, groups=1, relu=False, pool=None):
     """conv (+ BatchNorm + ReLU when `bn` is given) of the raw fp32 clip: layout "clip" = [B,T,C,H,W] evaluated
     per frame (time-major frames, 2-D kernel given as (1, kh, kw)), "volume" = [B,C,T,H,W] (3-D kernel)."""
     training = bn is not None and (bn.training or bn.running_mean is None)
     y, partial = _InputConv.apply(x, weight, bias, kernel, stride, padding, layout, dtype, groups if training else 0)
     if bn is None:
         return y
+    if pool is not None:  # (k, s, p) of the max-pool that follows BatchNorm + ReLU
+        return batch_norm_relu_pool(y, bn, groups, *pool, partial=partial if partial.numel() else None)
     return batch_norm(y, bn, groups, relu=relu, partial=partial if partial.numel() else None)
 
 
@@ -519,12 +521,14 @@ def conv(x, weight, bias=None, kernel=1, stride=1, padding=0, relu=False, out_f3
 
 
 def conv_bn(x, weight, bn, groups, bias=None, kernel=1, stride=1, padding=0, relu=False, residual=None, join=None,
-            res_join=None, grad_inplace=False):
+            res_join=None, grad_inplace=False, pool=None):
     """BatchNorm(conv(x)) (+ residual, ReLU).  In training the convolution's epilogue also writes the slab sums
     the BatchNorm statistics are taken from, where the geometry allows it (otherwise a separate pass reads y)."""
     training = bn.training or bn.running_mean is None
     y, partial = _Conv.apply(x, weight, bias, kernel, stride, padding, False, False, None, join,
                              groups if training else 0)
+    if pool is not None:  # (k, s, p) of the max-pool that follows BatchNorm + ReLU
+        return batch_norm_relu_pool(y, bn, groups, *pool, partial=partial if partial.numel() else None)
     return batch_norm(y, bn, groups, relu=relu, residual=residual, res_join=res_join,
                       partial=partial if partial.numel() else None, grad_inplace=grad_inplace)
 
@@ -663,6 +667,95 @@ def batch_norm(y, bn, groups, relu=False, residual=None, res_join=None, partial=
                            res_join, bn, partial, grad_inplace, tail)
     if tail is not None and tail.bits is not None:
         out._vc_bn_tail = tail
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += groups
+    return out
+
+
+class _BatchNormPool(torch.autograd.Function):
+    """max_pool(relu(batch_norm(y))) per frame without the full-resolution activation in between: y [N,D,H,W,C]
+    (N*D frames of H x W) -> [N,D,Ho,Wo,C]."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, groups, momentum, eps, training, owner, partial,
+                k, s, p):
+        _require_cuda(y, "batch_norm_pool")
+        y = y.contiguous()
+        N, D, H, W, C = y.shape
+        F_ = N * D
+        M = F_ * H * W
+        code = L.dtype_code(y.dtype)
+        dev = y.device
+        ga = gamma.detach() if gamma is not None else None
+        be = beta.detach() if beta is not None else None
+        if training:
+            G = groups
+            if F_ % G:
+                raise RuntimeError(f"batch_norm_pool: {F_} frames do not split into {G} groups")
+            rpg = M // G
+            sums = _zero_scratch(owner, "_vc_sums", (2, G, C), dev)
+            stat = torch.empty(4, G, C, device=dev, dtype=torch.float32)
+            if partial is not None:
+                L.call("vc_bn_stats_from_partial", L.ptr(partial), L.ptr(sums[0]), L.ptr(sums[1]), G, rpg // 64, C,
+                       L.stream())
+            else:
+                L.call("vc_bn_stats", code, L.ptr(y), L.ptr(sums[0]), L.ptr(sums[1]), G, rpg, C, L.stream())
+            L.call("vc_bn_finalize", L.ptr(sums[0]), L.ptr(sums[1]), L.ptr(ga), L.ptr(be), L.ptr(running_mean),
+                   L.ptr(running_var), L.ptr(stat[0]), L.ptr(stat[1]), L.ptr(stat[2]), L.ptr(stat[3]), G, C, rpg,
+                   float(eps), float(momentum), int(running_mean is not None) | 2, L.stream())
+        else:
+            G = 1
+            stat = torch.empty(4, 1, C, device=dev, dtype=torch.float32)
+            L.call("vc_bn_eval_params", L.ptr(ga), L.ptr(be), L.ptr(running_mean), L.ptr(running_var), L.ptr(stat[2]),
+                   L.ptr(stat[3]), C, float(eps), L.stream())
+        Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        out = torch.empty(N, D, Ho, Wo, C, device=dev, dtype=y.dtype)
+        idx = torch.empty(N, D, Ho, Wo, C, device=dev, dtype=torch.uint8)
+        L.call("vc_bn_pool_fwd", code, L.ptr(y), L.ptr(stat[2]), L.ptr(stat[3]), L.ptr(out), L.ptr(idx), F_, H, W, C,
+               k, s, p, F_ // G, L.stream())
+        ctx.geom = (F_, H, W, C, k, s, p, G)
+        ctx.training, ctx.owner, ctx.gamma, ctx.beta = training, owner, gamma, beta
+        ctx.save_for_backward(y, stat, idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if not ctx.training:
+            raise RuntimeError("batch_norm_pool: backward through eval-mode BatchNorm is not implemented")
+        y, stat, idx = ctx.saved_tensors
+        F_, H, W, C, k, s, p, G = ctx.geom
+        code = L.dtype_code(y.dtype)
+        dout = cast(dout.contiguous(), y.dtype)
+        sb = _zero_scratch(ctx.owner, "_vc_bsums", (2, G, C), y.device)  # cleared again by vc_bn_bwd_params
+        dy = torch.empty_like(y)
+        for phase in (0, 1):
+            L.call("vc_bn_pool_bwd", code, phase, L.ptr(y), L.ptr(dout), L.ptr(idx), L.ptr(stat[0]), L.ptr(stat[1]),
+                   L.ptr(stat[2]), L.ptr(stat[3]), L.ptr(sb[0]), L.ptr(sb[1]), L.ptr(dy), F_, H, W, C, k, s, p, G,
+                   L.stream())
+        dg = _grad_buf(ctx.gamma) if ctx.gamma is not None and ctx.gamma.requires_grad else None
+        db = _grad_buf(ctx.beta) if ctx.beta is not None and ctx.beta.requires_grad else None
+        L.call("vc_bn_bwd_params", L.ptr(sb[0]), L.ptr(sb[1]), L.ptr(dg), L.ptr(db), G, C, 3, L.stream())
+        _ready(ctx.gamma, ctx.beta)
+        return (dy,) + (None,) * 13
+
+
+# VC_FUSE_BN_POOL=0 keeps BatchNorm + ReLU and the max-pool that follows as two passes each way (A/B measurements)
+FUSE_BN_POOL = int(os.environ.get("VC_FUSE_BN_POOL", "1"))
+
+
+def batch_norm_relu_pool(y, bn, groups, k, s, p=0, partial=None):
+    """max_pool2d(relu(bn(y)), k, s, p) applied to every frame of y [N,D,H,W,C] (the max-pool never crosses D)."""
+    training = bn.training or bn.running_mean is None
+    # Overlapping windows (the ResNet stem's 3 / 2 / 1) re-read every input 2.25 times forward and gather up to four
+    # windows per element backward: measured no faster than the two-pass form there, so only k == s is fused by
+    # default (VC_FUSE_BN_POOL=2 fuses every geometry).
+    if FUSE_BN_POOL == 0 or (k != s and FUSE_BN_POOL != 2):
+        a = batch_norm(y, bn, groups, relu=True, partial=partial)
+        N, D, H, W, C = a.shape
+        o = max_pool2d(a.view(N * D, H, W, C), k, s, p)
+        return o.view(N, D, o.shape[1], o.shape[2], C)
+    out = _BatchNormPool.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, groups,
+                               bn.momentum if bn.momentum is not None else 0.1, bn.eps, training, bn, partial, k, s, p)
     if training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked += groups
     return out
