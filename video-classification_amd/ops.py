@@ -183,6 +183,8 @@ class _Conv(torch.autograd.Function):
                 pre_gelu=False):
         _require_cuda(x, "conv")
         ctx.join = join
+        # the slab-sum output never carries a gradient: do not let autograd fill a zero tensor of its size per call
+        ctx.set_materialize_grads(False)
         x = x.contiguous()
         # pre_gelu: the layer's input is gelu(x); x itself (the GELU's input) is what autograd differentiates, so
         # that the data-gradient GEMM can apply gelu' in its epilogue instead of a separate pass
@@ -264,6 +266,8 @@ class _Conv(torch.autograd.Function):
     def backward(ctx, dy, _dpartial=None):
         x, wt, y = ctx.saved_tensors
         co, ci, cip, cop = ctx.dims
+        if dy is None:  # nothing flows back into this layer
+            return (None,) * len(ctx.needs_input_grad)
         dtype = x.dtype
         code = L.dtype_code(dtype)
         dy = cast(dy.contiguous(), dtype)
@@ -379,6 +383,7 @@ class _InputConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, kernel, stride, padding, layout, dtype, stats_groups):
         _require_cuda(x, "input_conv")
+        ctx.set_materialize_grads(False)
         x = x.contiguous().float()
         k, s, p = _triple(kernel), _triple(stride), _triple(padding)
         if layout == "clip":      # [B,T,C,H,W] -> frames, time-major (frame = t*B + b), depth 1
@@ -443,6 +448,8 @@ class _InputConv(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dpartial=None):
+        if dy is None:
+            return (None,) * 9
         (U,) = ctx.saved_tensors
         co, ci, to, kw, Jp, cop = ctx.dims
         dtype = U.dtype
