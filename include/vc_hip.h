@@ -108,6 +108,11 @@ int vc_bn_stats_from_partial(const float* partial, float* sum, float* sumsq, int
 int vc_bn_finalize(float* sum, float* sumsq, const float* gamma, const float* beta, float* running_mean,
                    float* running_var, float* mean, float* invstd, float* scale, float* shift, int G, int C, int rpg,
                    float eps, float momentum, int flags, vc_stream_t stream);
+/* the same, and num_batches_tracked (device int64, nullable) += G in the same launch */
+int vc_bn_finalize_count(float* sum, float* sumsq, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, float* mean, float* invstd, float* scale, float* shift, int G, int C,
+                         int rpg, float eps, float momentum, int flags, int64_t* num_batches_tracked,
+                         vc_stream_t stream);
 int vc_bn_eval_params(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                       float* scale, float* shift, int C, float eps, vc_stream_t stream);
 int vc_bn_apply(int dtype, const void* y, const float* scale, const float* shift, const void* residual, void* out,

@@ -198,8 +198,9 @@ __global__ void bn_finalize_kernel(float* __restrict__ sum, float* __restrict__ 
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float* __restrict__ mean_out, float* __restrict__ invstd_out,
                                    float* __restrict__ scale, float* __restrict__ shift, int G, int C, float cnt,
-                                   float eps, float momentum, int flags) {
+                                   float eps, float momentum, int flags, int64_t* __restrict__ nbt) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt) *nbt += G;  // num_batches_tracked: one count per group (time step), as the per-step loop does
   if (c >= C) return;
   const int update_running = flags & 1;
   float rm = 0.f, rv = 0.f;
@@ -813,13 +814,28 @@ int vc_bn_bwd_sums_from_partial(const float* partial, const float* mean, const f
   return VC_OK;
 }
 
+int vc_bn_finalize_count(float* sum, float* sumsq, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, float* mean, float* invstd, float* scale, float* shift, int G, int C,
+                         int rpg, float eps, float momentum, int flags, int64_t* num_batches_tracked,
+                         hipStream_t stream);
+
 int vc_bn_finalize(float* sum, float* sumsq, const float* gamma, const float* beta, float* running_mean,
                    float* running_var, float* mean, float* invstd, float* scale, float* shift, int G, int C, int rpg,
                    float eps, float momentum, int flags, hipStream_t stream) {
+  return vc_bn_finalize_count(sum, sumsq, gamma, beta, running_mean, running_var, mean, invstd, scale, shift, G, C, rpg,
+                              eps, momentum, flags, nullptr, stream);
+}
+
+// vc_bn_finalize that also adds G to the module's num_batches_tracked (device int64, nullable) in the same launch
+int vc_bn_finalize_count(float* sum, float* sumsq, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, float* mean, float* invstd, float* scale, float* shift, int G, int C,
+                         int rpg, float eps, float momentum, int flags, int64_t* num_batches_tracked,
+                         hipStream_t stream) {
   VC_CHECK_ARG(sum && sumsq && mean && invstd && scale && shift, "vc_bn_finalize: null pointer");
   VC_CHECK_ARG(!(flags & 1) || (running_mean && running_var), "vc_bn_finalize: running stats missing");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, stream, sum, sumsq, gamma, beta,
-                     running_mean, running_var, mean, invstd, scale, shift, G, C, (float)rpg, eps, momentum, flags);
+                     running_mean, running_var, mean, invstd, scale, shift, G, C, (float)rpg, eps, momentum, flags,
+                     num_batches_tracked);
   VC_LAUNCH_CHECK("vc_bn_finalize");
   return VC_OK;
 }

@@ -556,6 +556,13 @@ def linear(x, weight, bias=None, relu=False, out_f32=False, residual=None, pre_g
 # ----------------------------------------------------------------------------------------------
 # BatchNorm with per-group (per time step) statistics
 # ----------------------------------------------------------------------------------------------
+def _nbt(bn):
+    """num_batches_tracked of a BatchNorm module when it lives on the GPU as int64 (it is then counted by the
+    finalize kernel itself), else None (the caller adds on the host side)."""
+    t = getattr(bn, "num_batches_tracked", None) if bn is not None else None
+    return t if (t is not None and t.is_cuda and t.dtype == torch.int64) else None
+
+
 class _BatchNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, gamma, beta, running_mean, running_var, groups, momentum, eps, relu, residual, training,
@@ -585,9 +592,9 @@ class _BatchNorm(torch.autograd.Function):
             else:
                 L.call("vc_bn_stats", code, L.ptr(y), L.ptr(sums[0]), L.ptr(sums[1]), G, rpg, C, L.stream())
             upd = running_mean is not None
-            L.call("vc_bn_finalize", L.ptr(sums[0]), L.ptr(sums[1]), L.ptr(ga), L.ptr(be), L.ptr(running_mean),
+            L.call("vc_bn_finalize_count", L.ptr(sums[0]), L.ptr(sums[1]), L.ptr(ga), L.ptr(be), L.ptr(running_mean),
                    L.ptr(running_var), L.ptr(stat[0]), L.ptr(stat[1]), L.ptr(stat[2]), L.ptr(stat[3]), G, C, rpg,
-                   float(eps), float(momentum), int(upd) | 2, L.stream())
+                   float(eps), float(momentum), int(upd) | 2, L.ptr(_nbt(owner)), L.stream())
         else:
             G, rpg = 1, M
             stat = torch.empty(4, 1, C, device=dev, dtype=torch.float32)
@@ -674,7 +681,7 @@ def batch_norm(y, bn, groups, relu=False, residual=None, res_join=None, partial=
                            res_join, bn, partial, grad_inplace, tail)
     if tail is not None and tail.bits is not None:
         out._vc_bn_tail = tail
-    if training and bn.num_batches_tracked is not None:
+    if training and bn.num_batches_tracked is not None and _nbt(bn) is None:
         bn.num_batches_tracked += groups
     return out
 
@@ -707,9 +714,9 @@ class _BatchNormPool(torch.autograd.Function):
                        L.stream())
             else:
                 L.call("vc_bn_stats", code, L.ptr(y), L.ptr(sums[0]), L.ptr(sums[1]), G, rpg, C, L.stream())
-            L.call("vc_bn_finalize", L.ptr(sums[0]), L.ptr(sums[1]), L.ptr(ga), L.ptr(be), L.ptr(running_mean),
+            L.call("vc_bn_finalize_count", L.ptr(sums[0]), L.ptr(sums[1]), L.ptr(ga), L.ptr(be), L.ptr(running_mean),
                    L.ptr(running_var), L.ptr(stat[0]), L.ptr(stat[1]), L.ptr(stat[2]), L.ptr(stat[3]), G, C, rpg,
-                   float(eps), float(momentum), int(running_mean is not None) | 2, L.stream())
+                   float(eps), float(momentum), int(running_mean is not None) | 2, L.ptr(_nbt(owner)), L.stream())
         else:
             G = 1
             stat = torch.empty(4, 1, C, device=dev, dtype=torch.float32)
@@ -763,7 +770,7 @@ def batch_norm_relu_pool(y, bn, groups, k, s, p=0, partial=None):
         return o.view(N, D, o.shape[1], o.shape[2], C)
     out = _BatchNormPool.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, groups,
                                bn.momentum if bn.momentum is not None else 0.1, bn.eps, training, bn, partial, k, s, p)
-    if training and bn.num_batches_tracked is not None:
+    if training and bn.num_batches_tracked is not None and _nbt(bn) is None:
         bn.num_batches_tracked += groups
     return out
 
