@@ -265,6 +265,22 @@ int vc_optim_step(int mode, float* p, const float* g, float* m, float* v, int64_
  * that a hipGraph of the whole training step replays with current values */
 int vc_counter_add(int64_t* counter, int64_t inc, vc_stream_t stream);
 
+/* ---- per-frame input transform (the reference's host-side PIL + torchvision chain, per frame:
+ * utils/common/data_loaders.py:39-51, 88-100 with the transform of train.py:344-388) ---------------------------
+ * vc_resample_ksize / vc_resample_coeffs are HOST functions: window bounds [out_size][2] (first source index, tap
+ * count) and 22-bit fixed-point weights [out_size][ksize] of Pillow's anti-aliased bilinear filter for a resize
+ * of in_size to out_size samples; vc_resample_coeffs returns ksize.  The caller copies both tables to the device.
+ * vc_frames_transform: frames uint8 [n][hs][ws][3] (RGB, 16-byte aligned base) -> out [n][C][hd][wd] of out_dtype,
+ * C = 1 if gray (convert('L') before the resize, Dataset_3DCNN) else 3: Resize([hd, wd]) -> flip of the frames
+ * with flip[i] != 0 (nullable; one flag per frame, the reference draws RandomHorizontalFlip per frame) -> ToTensor
+ * -> Normalize(mean[C], std[C]).  Integer-exact with Pillow up to the uint8 frame, fp32 output bit-identical to
+ * the host chain.  RandomCrop(size) after Resize to the same size is the identity; ColorJitter is not provided. */
+int vc_resample_ksize(int in_size, int out_size);
+int vc_resample_coeffs(int in_size, int out_size, int* bounds, int* kk);
+int vc_frames_transform(const void* frames, int n, int hs, int ws, int gray, int hd, int wd, const int* xbounds,
+                        const int* xk, int ksx, const int* ybounds, const int* yk, int ksy, const void* flip,
+                        const float* mean, const float* stdv, void* out, int out_dtype, vc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,176 @@
+"""Per-frame input transform (reference: train.py:344-388 applied per frame by utils/common/data_loaders.py:39-51,
+88-100).  CPU tests pin the numpy oracle to the Pillow-made fixtures and to Pillow itself, and the library's host
+coefficient routine to the oracle; GPU tests hold the HIP kernel to the oracle bit for bit."""
+import ctypes
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import frames_oracle as FO
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FIXTURES = sorted(glob.glob(os.path.join(GOLD, "frames_*.npz")))
+
+
+def _load(path):
+    z = np.load(path)  # plain arrays, no pickles
+    return {k: z[k] for k in z.files}
+
+
+def test_fixtures_present():
+    assert len(FIXTURES) == 4
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[:-4] for p in FIXTURES])
+def test_oracle_matches_pillow_fixtures(path):
+    z = _load(path)
+    gray = bool(z["gray"])
+    h, w = (int(v) for v in z["size"])
+    for i in range(z["frames"].shape[0]):
+        f = FO.rgb_to_l(z["frames"][i]) if gray else z["frames"][i]
+        r = FO.resize_bilinear_u8(f, h, w)
+        if z["flip"][i]:
+            r = r[:, ::-1]
+        assert np.array_equal(r, z["resized_u8"][i])
+    out = FO.transform_frames(z["frames"], h, w, z["mean"], z["std"], z["flip"], gray)
+    assert out.dtype == np.float32 and np.array_equal(out, z["out"])  # bit-exact float32
+
+
+@pytest.mark.parametrize("hs,ws,hd,wd", [(256, 340, 224, 224), (240, 320, 112, 112), (50, 70, 224, 224),
+                                         (1080, 1920, 224, 224), (225, 223, 224, 224), (17, 9, 5, 3)])
+def test_oracle_matches_pillow_live(hs, ws, hd, wd):
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(hs * 7 + ws)
+    a = rng.integers(0, 256, (hs, ws, 3), dtype=np.uint8)
+    assert np.array_equal(FO.resize_bilinear_u8(a, hd, wd), np.asarray(Image.fromarray(a).resize((wd, hd), Image.BILINEAR)))
+    lum = np.asarray(Image.fromarray(a).convert("L"))
+    assert np.array_equal(FO.rgb_to_l(a), lum)
+    assert np.array_equal(FO.resize_bilinear_u8(lum, hd, wd),
+                          np.asarray(Image.fromarray(lum).resize((wd, hd), Image.BILINEAR)))
+
+
+@pytest.mark.parametrize("n_in,n_out", [(340, 224), (256, 224), (320, 112), (240, 112), (224, 224), (70, 224),
+                                        (1920, 224), (9, 3), (1, 1), (1, 5), (1000, 1)])
+def test_host_coefficients_match_oracle(n_in, n_out):
+    from video_classification_amd import frames as FR
+    b, k = FR.resample_coeffs(n_in, n_out)
+    ob, ok = FO.resample_coeffs(n_in, n_out)
+    assert k.shape == ok.shape
+    assert np.array_equal(b, ob) and np.array_equal(k, ok)
+    assert (k.sum(axis=1) - (1 << 22)).__abs__().max() <= k.shape[1]  # weights sum to one in fixed point
+
+
+def test_transform_argument_checks():
+    from video_classification_amd import _lib as L
+    lib = L.lib()
+    lib.vc_last_error.restype = ctypes.c_char_p
+    rc = lib.vc_frames_transform(None, 2, 64, 85, 0, 56, 56, None, None, 3, None, None, 5, None, None, None, None, 0,
+                                 None)
+    assert rc == -4 and b"another geometry" in lib.vc_last_error()
+    assert lib.vc_frames_transform(None, 0, 64, 85, 0, 56, 56, None, None, 5, None, None, 5, None, None, None, None,
+                                   0, None) == 0  # no frames: nothing to do
+    assert lib.vc_frames_transform(None, 2, 64, 85, 0, 56, 56, None, None, 5, None, None, 5, None, None, None, None,
+                                   7, None) == -4
+    from video_classification_amd import frames as FR
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        FR.FrameTransform(8, device="cpu")(torch.zeros(1, 4, 4, 3, dtype=torch.uint8))
+
+
+def test_raw_dataset_reads_what_pillow_decodes(tmp_path):
+    Image = pytest.importorskip("PIL.Image")
+    from video_classification_amd import frames as FR
+    rng = np.random.default_rng(0)
+    for folder in ("v_A_g01_c01", "v_B_g02_c03"):
+        os.makedirs(tmp_path / folder)
+        for i in range(1, 6):
+            Image.fromarray(rng.integers(0, 256, (24, 32, 3), dtype=np.uint8)).save(
+                str(tmp_path / folder / f"frame{i:06d}.jpg"), quality=90)
+    ds = FR.RawFrameDataset(str(tmp_path), ["v_A_g01_c01", "v_B_g02_c03"], [3, 7], [1, 3, 5])
+    assert len(ds) == 2
+    x, y = ds[1]
+    assert x.dtype == torch.uint8 and tuple(x.shape) == (3, 24, 32, 3)
+    assert y.dtype == torch.int64 and y.tolist() == [7]
+    want = np.asarray(Image.open(str(tmp_path / "v_B_g02_c03" / "frame000003.jpg")))
+    assert np.array_equal(x[1].numpy(), want)
+    clips, target = FR.raw_collate([ds[0], ds[1]])
+    assert len(clips) == 2 and tuple(target.shape) == (2, 1)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[:-4] for p in FIXTURES])
+def test_gpu_transform_matches_fixtures(cuda, path):
+    from video_classification_amd import frames as FR
+    z = _load(path)
+    tf = FR.FrameTransform(tuple(int(v) for v in z["size"]), z["mean"].tolist(), z["std"].tolist(),
+                           gray=bool(z["gray"]), device=cuda)
+    out = tf(torch.from_numpy(z["frames"]).to(cuda), torch.from_numpy(z["flip"]).to(cuda))
+    assert np.array_equal(out.cpu().numpy(), z["out"])  # bit-exact float32
+    tf16 = FR.FrameTransform(tuple(int(v) for v in z["size"]), z["mean"].tolist(), z["std"].tolist(),
+                             gray=bool(z["gray"]), device=cuda, dtype=torch.bfloat16)
+    out16 = tf16(torch.from_numpy(z["frames"]).to(cuda), torch.from_numpy(z["flip"]).to(cuda))
+    assert torch.equal(out16.cpu(), torch.from_numpy(z["out"]).to(torch.bfloat16))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,hs,ws,size,gray", [
+    (6, 256, 340, 224, False),    # jpegs_256 frames of UCF101 -> the colour models
+    (6, 240, 320, 112, True),     # Conv3D
+    (3, 256, 341, 224, False),    # odd row length: no frame but the first starts on a 16-byte boundary
+    (2, 50, 70, 224, False),      # up-scaling
+    (2, 1080, 1920, 224, False),  # 8.6x reduction: 19-tap windows, row blocks of more than 64 KB
+    (2, 224, 224, 224, False),    # nothing to resize
+    (1, 7, 5, (3, 9), True),
+])
+def test_gpu_transform_full_size(cuda, n, hs, ws, size, gray):
+    from video_classification_amd import frames as FR
+    rng = np.random.default_rng(n * 1000 + hs + ws)
+    frames = rng.integers(0, 256, (n, hs, ws, 3), dtype=np.uint8)
+    flip = (rng.random(n) < 0.5).astype(np.uint8)
+    flip[-1] = 1
+    mean, std = ([0.5], [0.5]) if gray else (FR.IMAGENET_MEAN, FR.IMAGENET_STD)
+    tf = FR.FrameTransform(size, mean, std, gray=gray, device=cuda)
+    out = tf(torch.from_numpy(frames).to(cuda), torch.from_numpy(flip).to(cuda)).cpu().numpy()
+    want = FO.transform_frames(frames, tf.hd, tf.wd, mean, std, flip, gray)
+    assert out.shape == want.shape
+    assert np.array_equal(out, want)
+    # clip-shaped input [B, T, H, W, 3] -> [B, T, C, S, S], no flip
+    if n % 2 == 0:
+        out2 = tf(torch.from_numpy(frames).to(cuda).view(2, n // 2, hs, ws, 3)).cpu().numpy()
+        want2 = FO.transform_frames(frames, tf.hd, tf.wd, mean, std, None, gray)
+        assert out2.shape == (2, n // 2) + want2.shape[1:]
+        assert np.array_equal(out2.reshape(want2.shape), want2)
+
+
+@pytest.mark.gpu
+def test_gpu_prefetcher_yields_reference_batches(cuda):
+    from video_classification_amd import frames as FR
+    rng = np.random.default_rng(11)
+    batches = []
+    for b in range(3):
+        clips = [torch.from_numpy(rng.integers(0, 256, (4, 48, 64, 3), dtype=np.uint8)) for _ in range(3)]
+        if b == 1:  # one clip of another frame size in the batch
+            clips[2] = torch.from_numpy(rng.integers(0, 256, (4, 40, 40, 3), dtype=np.uint8))
+        batches.append((clips, torch.tensor([[b], [b + 1], [b + 2]])))
+    tf = FR.FrameTransform(32, device=cuda)
+    gen = torch.Generator().manual_seed(5)
+    got = list(FR.DevicePrefetcher(batches, tf, flip_p=0.5, generator=gen))
+    gen = torch.Generator().manual_seed(5)
+    assert len(got) == 3
+    for (clips, target), (x, y) in zip(batches, got):
+        flip = (torch.rand(12, generator=gen) < 0.5).numpy().reshape(3, 4)
+        assert x.device.type == "cuda" and tuple(x.shape) == (3, 4, 3, 32, 32) and x.dtype == torch.float32
+        assert torch.equal(y.cpu(), target)
+        for i, cl in enumerate(clips):
+            want = FO.transform_frames(cl.numpy(), 32, 32, FR.IMAGENET_MEAN, FR.IMAGENET_STD, flip[i])
+            assert np.array_equal(x[i].cpu().numpy(), want)
+    # gray pipeline hands out Conv3D's [B, 1, T, S, S]
+    tfg = FR.FrameTransform(16, [0.5], [0.5], gray=True, device=cuda)
+    stacked = [(torch.stack(c[0][:2]), c[1][:2]) for c in batches[:1]]
+    (x, y), = list(FR.DevicePrefetcher(stacked, tfg))
+    assert tuple(x.shape) == (2, 1, 4, 16, 16)
+    want = FO.transform_frames(stacked[0][0][1].numpy(), 16, 16, [0.5], [0.5], None, True)
+    assert np.array_equal(x[1, 0].cpu().numpy(), want[:, 0])

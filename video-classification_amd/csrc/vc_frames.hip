@@ -1,0 +1,264 @@
+// Per-frame input transform on the GPU: decoded uint8 frames [N, Hs, Ws, 3] -> normalised planar float / bf16
+// frames [N, C, Hd, Wd], the chain the reference runs per frame on the host with PIL + torchvision
+// (train.py:344-388; utils/common/data_loaders.py:39-51, 88-100):
+//   [convert('L')] -> Resize (Pillow's anti-aliased bilinear, 8-bit fixed point) -> [horizontal flip]
+//   -> ToTensor (/255) -> Normalize ((x - mean) / std).
+// Integer-exact with Pillow: 22-bit fixed-point weights, int32 accumulation from 1 << 21, >> 22, clip to 0..255,
+// horizontal pass first and its uint8 result feeding the vertical pass; the float tail uses correctly rounded
+// IEEE division, so the fp32 output is bit-identical to the host chain as well.
+//
+// One workgroup produces TY output rows of one frame.  The source rows it needs are one contiguous byte range of
+// the frame; they are copied to LDS with 16-byte loads, reduced horizontally into a uint8 LDS tile and reduced
+// vertically from there, so HBM sees every source byte about once and every output element exactly once.
+#include <math.h>
+
+#include "vc_common.h"
+
+namespace {
+
+constexpr int PREC = 22;  // 32 - 8 - 2, Pillow's PRECISION_BITS
+constexpr int FT_THREADS = 256;
+constexpr int FT_MAX_LDS = 150 * 1024;
+
+struct FrameGeom {
+  int n, hs, ws, hd, wd;
+  int co;        // output channels: 3, or 1 when gray
+  int gray;      // RGB -> L before the resize
+  int ksx, ksy;  // row strides of the weight tables
+  int ty;        // output rows per workgroup
+  int cap_rows;  // most source rows a workgroup can need
+  int raw_bytes, lum_bytes;
+  FastDiv f_wdco, f_co, f_wd, f_ws;
+};
+
+__device__ __forceinline__ int clip8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+
+template <typename OUT>
+__global__ __launch_bounds__(FT_THREADS) void frames_transform_kernel(FrameGeom g, const uint8_t* __restrict__ src,
+                                                                      const int* __restrict__ xb,
+                                                                      const int* __restrict__ xk,
+                                                                      const int* __restrict__ yb,
+                                                                      const int* __restrict__ yk,
+                                                                      const uint8_t* __restrict__ flip,
+                                                                      const float* __restrict__ mean,
+                                                                      const float* __restrict__ stdv,
+                                                                      OUT* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  uint8_t* raw = lds;                               // source rows (RGB), starting `mis` bytes in
+  uint8_t* lum = lds + g.raw_bytes;                 // gray only: luma of the source rows
+  uint8_t* tmp = lds + g.raw_bytes + g.lum_bytes;   // horizontally reduced rows [nrows][wd][co]
+
+  const int tid = threadIdx.x;
+  const int n = blockIdx.y;
+  const int y0 = blockIdx.x * g.ty;
+  const int y1 = min(y0 + g.ty, g.hd);
+
+  // source rows [r0, r0 + nrows) feed the output rows [y0, y1); tables are clamped so that a table of another
+  // geometry can produce wrong pixels but never an access outside the frame
+  int r0 = yb[2 * y0];
+  int rend = yb[2 * (y1 - 1)] + yb[2 * (y1 - 1) + 1];
+  r0 = max(0, min(r0, g.hs - 1));
+  rend = max(r0 + 1, min(rend, g.hs));
+  const int nrows = min(rend - r0, g.cap_rows);
+
+  // --- stage the source rows: one contiguous byte range, 16-byte loads from a 16-byte aligned start ---
+  const size_t row_bytes = (size_t)g.ws * 3;
+  const uint8_t* gsrc = src + ((size_t)n * g.hs + r0) * row_bytes;
+  const uint8_t* gend = src + (size_t)g.n * g.hs * row_bytes;
+  const int mis = (int)(reinterpret_cast<uintptr_t>(gsrc) & 15);
+  const uint8_t* gbase = gsrc - mis;  // >= src because src itself is 16-byte aligned
+  const int nvec = (mis + nrows * (int)row_bytes + 15) >> 4;
+  for (int i = tid; i < nvec; i += FT_THREADS) {
+    const uint8_t* p = gbase + (size_t)i * 16;
+    if (p + 16 <= gend) {
+      *reinterpret_cast<uint4*>(raw + i * 16) = *reinterpret_cast<const uint4*>(p);
+    } else {
+      for (int b = 0; b < 16; ++b) raw[i * 16 + b] = (p + b < gend) ? p[b] : (uint8_t)0;
+    }
+  }
+  __syncthreads();
+
+  const uint8_t* hsrc = raw + mis;  // [nrows][ws][3]
+  int cs = 3;
+  if (g.gray) {
+    const int npix = nrows * g.ws;
+    for (int i = tid; i < npix; i += FT_THREADS) {
+      const uint8_t* p = hsrc + i * 3;
+      lum[i] = (uint8_t)((p[0] * 19595 + p[1] * 38470 + p[2] * 7471 + 0x8000) >> 16);
+    }
+    __syncthreads();
+    hsrc = lum;
+    cs = 1;
+  }
+
+  // --- horizontal pass into tmp ---
+  const int wdco = g.wd * g.co;
+  const int hitems = nrows * wdco;
+  for (int i = tid; i < hitems; i += FT_THREADS) {
+    int r, rem, x, c;
+    fd_divmod(i, g.f_wdco, r, rem);
+    fd_divmod(rem, g.f_co, x, c);
+    int cnt = min(min(xb[2 * x + 1], g.ksx), g.ws);
+    int x0 = max(0, min(xb[2 * x], g.ws - cnt));
+    const int* k = xk + x * g.ksx;
+    const uint8_t* p = hsrc + ((size_t)r * g.ws + x0) * cs + c;
+    int acc = 1 << (PREC - 1);
+    for (int t = 0; t < cnt; ++t) acc += (int)p[t * cs] * k[t];
+    tmp[i] = (uint8_t)clip8(acc >> PREC);
+  }
+  __syncthreads();
+
+  // --- vertical pass, ToTensor, Normalize, flip; x fastest so that stores coalesce ---
+  const bool fl = flip != nullptr && flip[n] != 0;
+  const int vitems = (y1 - y0) * wdco;
+  for (int i = tid; i < vitems; i += FT_THREADS) {
+    int t2, x, yy, c;
+    fd_divmod(i, g.f_wd, t2, x);
+    fd_divmod(t2, g.f_co, yy, c);
+    const int y = y0 + yy;
+    int q0 = max(0, min(yb[2 * y] - r0, nrows - 1));
+    int cnt = min(min(yb[2 * y + 1], g.ksy), nrows - q0);
+    const int* k = yk + y * g.ksy;
+    const uint8_t* p = tmp + ((size_t)q0 * g.wd + x) * g.co + c;
+    int acc = 1 << (PREC - 1);
+    for (int t = 0; t < cnt; ++t) acc += (int)p[t * wdco] * k[t];
+    const int v = clip8(acc >> PREC);
+    float f = (float)v / 255.0f;
+    f = (f - mean[c]) / stdv[c];
+    const int xo = fl ? g.wd - 1 - x : x;
+    out[(((size_t)n * g.co + c) * g.hd + y) * g.wd + xo] = from_f32<OUT>(f);
+  }
+}
+
+// rows of the source a block of `ty` output rows can touch (window of the first row to window of the last)
+int rows_cap(int hs, int hd, int ty) {
+  const double scale = (double)hs / hd;
+  const double support = scale < 1.0 ? 1.0 : scale;
+  const int cap = (int)floor((ty - 1) * scale + 2.0 * support + 1.0) + 2;
+  return cap < hs ? cap : hs;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vc_resample_ksize(int in_size, int out_size) {
+  if (in_size < 1 || out_size < 1) return VC_ERR_ARG;
+  double scale = (double)in_size / out_size;
+  if (scale < 1.0) scale = 1.0;
+  return (int)ceil(scale) * 2 + 1;
+}
+
+// Host code only.  Same operations in the same order as Pillow's precompute_coeffs + normalize_coeffs_8bpc
+// (triangle filter, full-extent box), in double precision.
+int vc_resample_coeffs(int in_size, int out_size, int* bounds, int* kk) {
+  VC_CHECK_ARG(in_size >= 1 && out_size >= 1 && bounds && kk, "vc_resample_coeffs: bad arguments");
+  const double scale = (double)in_size / out_size;
+  const double filterscale = scale < 1.0 ? 1.0 : scale;
+  const double support = 1.0 * filterscale;
+  const int ksize = (int)ceil(support) * 2 + 1;
+  const double ss = 1.0 / filterscale;
+  double* w = new double[ksize];
+  for (int xx = 0; xx < out_size; ++xx) {
+    const double center = (xx + 0.5) * scale;
+    int xmin = (int)(center - support + 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5);
+    if (xmax > in_size) xmax = in_size;
+    xmax -= xmin;
+    double ww = 0.0;
+    for (int x = 0; x < ksize; ++x) w[x] = 0.0;
+    for (int x = 0; x < xmax; ++x) {
+      double a = (x + xmin - center + 0.5) * ss;
+      if (a < 0.0) a = -a;
+      w[x] = a < 1.0 ? 1.0 - a : 0.0;
+      ww += w[x];
+    }
+    for (int x = 0; x < xmax; ++x)
+      if (ww != 0.0) w[x] /= ww;
+    for (int x = 0; x < ksize; ++x) {
+      const double v = w[x] * (double)(1 << PREC);
+      kk[xx * ksize + x] = w[x] < 0 ? (int)(-0.5 + v) : (int)(0.5 + v);
+    }
+    bounds[2 * xx] = xmin;
+    bounds[2 * xx + 1] = xmax;
+  }
+  delete[] w;
+  return ksize;
+}
+
+int vc_frames_transform(const void* frames, int n, int hs, int ws, int gray, int hd, int wd, const int* xbounds,
+                        const int* xk, int ksx, const int* ybounds, const int* yk, int ksy, const void* flip,
+                        const float* mean, const float* stdv, void* out, int out_dtype, hipStream_t stream) {
+  VC_CHECK_SHAPE(n >= 0 && hs >= 1 && ws >= 1 && hd >= 1 && wd >= 1, "vc_frames_transform: bad extents");
+  VC_CHECK_ARG(out_dtype == VC_F32 || out_dtype == VC_BF16, "vc_frames_transform: dtype %d", out_dtype);
+  VC_CHECK_ARG(ksx == vc_resample_ksize(ws, wd) && ksy == vc_resample_ksize(hs, hd),
+               "vc_frames_transform: weight tables of another geometry (ksize %d/%d, expected %d/%d)", ksx, ksy,
+               vc_resample_ksize(ws, wd), vc_resample_ksize(hs, hd));
+  if (n == 0) return VC_OK;
+  VC_CHECK_ARG(frames && xbounds && xk && ybounds && yk && mean && stdv && out, "vc_frames_transform: null pointer");
+  VC_CHECK_ARG((reinterpret_cast<uintptr_t>(frames) & 15) == 0, "vc_frames_transform: frames must be 16-byte aligned");
+  VC_CHECK_SHAPE(n <= 65535, "vc_frames_transform: at most 65535 frames per call (got %d)", n);
+  VC_CHECK_SHAPE((int64_t)hs * ws * 3 < (1ll << 31) && (int64_t)hd * wd * 3 < (1ll << 31),
+                 "vc_frames_transform: frame too large");
+
+  FrameGeom g;
+  memset(&g, 0, sizeof(g));
+  g.n = n; g.hs = hs; g.ws = ws; g.hd = hd; g.wd = wd;
+  g.gray = gray ? 1 : 0;
+  g.co = gray ? 1 : 3;
+  g.ksx = ksx; g.ksy = ksy;
+  int lds = 0;
+  // the largest block of rows whose tiles stay small enough for several workgroups per CU; smaller blocks for
+  // wide or strongly reduced frames, down to one row
+  const int tys[] = {16, 8, 4, 2, 1};
+  for (int pass = 0; pass < 2 && lds == 0; ++pass) {
+    const int limit = pass == 0 ? 40 * 1024 : FT_MAX_LDS;
+    for (int ty : tys) {
+      const int cap = rows_cap(hs, hd, ty);
+      const int raw = ((cap * ws * 3 + 15 + 15) & ~15) + 16;
+      const int lum = gray ? ((cap * ws + 15) & ~15) : 0;
+      const int tmp = (cap * wd * g.co + 15) & ~15;
+      if (raw + lum + tmp <= limit) {
+        g.ty = ty; g.cap_rows = cap; g.raw_bytes = raw; g.lum_bytes = lum;
+        lds = raw + lum + tmp;
+        break;
+      }
+    }
+  }
+  VC_CHECK_SHAPE(lds > 0, "vc_frames_transform: %d x %d -> %d x %d needs more than %d bytes of LDS per row block",
+                 hs, ws, hd, wd, FT_MAX_LDS);
+  g.f_wdco = make_fastdiv(wd * g.co);
+  g.f_co = make_fastdiv(g.co);
+  g.f_wd = make_fastdiv(wd);
+  g.f_ws = make_fastdiv(ws);
+
+  dim3 grid(ceil_div(hd, g.ty), n);
+  const uint8_t* s = static_cast<const uint8_t*>(frames);
+  const uint8_t* fl = static_cast<const uint8_t*>(flip);
+  if (out_dtype == VC_F32) {
+    auto kern = frames_transform_kernel<float>;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+            hipSuccess) {
+      vc_set_error("vc_frames_transform: cannot reserve %d bytes of LDS", lds);
+      return VC_ERR_HIP;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(FT_THREADS), lds, stream, g, s, xbounds, xk, ybounds, yk, fl, mean, stdv,
+                       static_cast<float*>(out));
+  } else {
+    auto kern = frames_transform_kernel<bf16>;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+            hipSuccess) {
+      vc_set_error("vc_frames_transform: cannot reserve %d bytes of LDS", lds);
+      return VC_ERR_HIP;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(FT_THREADS), lds, stream, g, s, xbounds, xk, ybounds, yk, fl, mean, stdv,
+                       static_cast<bf16*>(out));
+  }
+  VC_LAUNCH_CHECK("vc_frames_transform");
+  return VC_OK;
+}
+
+}  // extern "C"

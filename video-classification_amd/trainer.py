@@ -380,13 +380,18 @@ def validate_epoch(model, val_loader, criterion, device, epoch, use_amp=False, l
     return total_loss.item() / max(nb, 1), 100. * correct.item() / max(total, 1)
 
 
-def save_checkpoint(model, optimizer, epoch, loss, save_path):
-    """Same dictionary as the reference (training_utils.py:212-219), written from rank 0 only."""
+def save_checkpoint(model, optimizer, epoch, loss, save_path, scheduler=None):
+    """Same dictionary as the reference (training_utils.py:212-219), written from rank 0 only.  With a scheduler
+    its state goes in as one more key, ``scheduler_state_dict``; the reference's loader ignores keys it does not
+    know, so the file stays loadable there."""
     if dist.is_initialized() and dist.get_rank() != 0:
         return
     os.makedirs(os.path.dirname(save_path) or ".", exist_ok=True)
-    torch.save({"epoch": epoch, "model_state_dict": model.state_dict(),
-                "optimizer_state_dict": optimizer.state_dict(), "loss": loss}, save_path)
+    ckpt = {"epoch": epoch, "model_state_dict": model.state_dict(),
+            "optimizer_state_dict": optimizer.state_dict(), "loss": loss}
+    if scheduler is not None:
+        ckpt["scheduler_state_dict"] = scheduler.state_dict()
+    torch.save(ckpt, save_path)
 
 
 def strip_module_prefix(state_dict):
@@ -394,16 +399,62 @@ def strip_module_prefix(state_dict):
     return {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
 
 
-def load_checkpoint(model, optimizer, checkpoint_path):
-    """Returns the epoch to start from (training_utils.py:222-243); accepts DataParallel-prefixed keys."""
+def restore_scheduler(scheduler, ckpt, optimizer=None):
+    """Puts a learning-rate scheduler where it stood when `ckpt` was written.  A checkpoint of this trainer
+    carries the scheduler's own state.  One written by the reference does not (training_utils.py:212-217); its
+    optimizer state holds the learning rate of that moment, so for the epoch-driven schedules (StepLR,
+    CosineAnnealingLR: training_utils.py:345-348) setting the epoch counter is enough; ReduceLROnPlateau keeps the
+    restored learning rate and starts its patience window afresh (its history was never saved)."""
+    if scheduler is None:
+        return
+    if "scheduler_state_dict" in ckpt:
+        scheduler.load_state_dict(ckpt["scheduler_state_dict"])
+    elif not isinstance(scheduler, torch.optim.lr_scheduler.ReduceLROnPlateau):
+        done = int(ckpt["epoch"])  # scheduler.step() ran once per finished epoch (train.py:668-683)
+        scheduler.last_epoch = done
+        scheduler._step_count = done + 1
+        scheduler._last_lr = [g["lr"] for g in scheduler.optimizer.param_groups]
+    opt = optimizer if optimizer is not None else getattr(scheduler, "optimizer", None)
+    if isinstance(opt, FusedOptimizer):
+        opt._lr_host = None
+        opt.sync_lr()
+
+
+def load_checkpoint(model, optimizer, checkpoint_path, scheduler=None):
+    """Returns the epoch to start from (training_utils.py:222-243); accepts DataParallel-prefixed keys.  Unlike
+    the reference's resume branch (train.py:848-873 only checks that the file exists) the states are restored:
+    weights and buffers, optimizer moments and step count, the learning rate on the device, the scheduler, and the
+    packed bf16 copies of the weights are marked stale so that the next forward rebuilds them."""
     if not os.path.exists(checkpoint_path):
         return 1
     ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
     model.load_state_dict(strip_module_prefix(ckpt["model_state_dict"]))
     if optimizer is not None and "optimizer_state_dict" in ckpt:
         optimizer.load_state_dict(ckpt["optimizer_state_dict"])
+    restore_scheduler(scheduler, ckpt, optimizer)
     ops.bump_weights_epoch()
     return ckpt["epoch"] + 1
+
+
+def checkpoint_path_for_epoch(ckpt_dir, epoch):
+    """File name the reference's training loop gives the checkpoint of a finished epoch (train.py:699, 859)."""
+    return os.path.join(ckpt_dir, f"checkpoint_epoch_{epoch}.pth")
+
+
+def resume_training(model, optimizer, scheduler, ckpt_dir, resume_epoch):
+    """``--resume N`` of the reference (train.py:779-780, 848-873) carried through: finds
+    ``checkpoint_epoch_N.pth`` under `ckpt_dir`, restores model, optimizer and scheduler, and returns the epoch
+    to continue with (N + 1).  Raises FileNotFoundError naming the checkpoints that do exist (the reference
+    prints the same list and gives up)."""
+    path = checkpoint_path_for_epoch(ckpt_dir, resume_epoch)
+    if not os.path.exists(path):
+        have = sorted(f for f in os.listdir(ckpt_dir) if f.startswith("checkpoint_epoch_")) \
+            if os.path.isdir(ckpt_dir) else []
+        raise FileNotFoundError(f"no checkpoint of epoch {resume_epoch} under {ckpt_dir}; available: {have}")
+    if dist.is_initialized():
+        # every rank reads the same file, so replicas restart identical without a broadcast
+        dist.barrier()
+    return load_checkpoint(model, optimizer, path, scheduler)
 
 
 # --------------------------------------------------------------------------------------
