@@ -17,21 +17,50 @@
 namespace {
 
 constexpr int PREC = 22;  // 32 - 8 - 2, Pillow's PRECISION_BITS
-constexpr int FT_THREADS = 256;
+constexpr int FT_THREADS = 512;
 constexpr int FT_MAX_LDS = 150 * 1024;
 
 struct FrameGeom {
   int n, hs, ws, hd, wd;
   int co;        // output channels: 3, or 1 when gray
   int gray;      // RGB -> L before the resize
-  int ksx, ksy;  // row strides of the weight tables
+  int ksx, ksy;  // row strides of the weight tables in global memory
+  int kpx;       // ksx rounded up to a multiple of 4: taps are multiplied four at a time, the surplus with weight 0
+  int wdp;       // wd rounded up to a multiple of 4: row stride of a plane of the horizontally reduced tile
   int ty;        // output rows per workgroup
   int cap_rows;  // most source rows a workgroup can need
-  int raw_bytes, lum_bytes;
-  FastDiv f_wdco, f_co, f_wd, f_ws;
+  int raw_bytes, lum_bytes, tmp_bytes;  // LDS regions, each a multiple of 16 bytes
+  FastDiv f_wd, f_w4, f_co;
 };
 
 __device__ __forceinline__ int clip8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+__device__ __forceinline__ int byte_of(uint32_t d, int j) { return (int)((d >> (8 * j)) & 0xffu); }
+// byte x weight: the weights of the triangle filter lie in 0 .. 2^22, so the 24-bit multiplier (full rate) is exact
+__device__ __forceinline__ int mul24(int b, int w) { return (int)__umul24((unsigned)b, (unsigned)w); }
+
+// One pixel of the horizontal pass: CS interleaved channels, taps x0 .. x0 + 4 * ng - 1 of one LDS row, weights k
+// (zero beyond the window).  The bytes are fetched as aligned dwords and shifted into place.
+template <int CS>
+__device__ __forceinline__ void hpass_pixel(const uint8_t* rowbytes, int b0, const int* k, int ng, int (&acc)[CS]) {
+  const uint32_t* d = reinterpret_cast<const uint32_t*>(rowbytes + (b0 & ~3));
+  const uint32_t sh = (uint32_t)(b0 & 3);
+#pragma unroll
+  for (int c = 0; c < CS; ++c) acc[c] = 1 << (PREC - 1);
+  uint32_t d0 = d[0];
+  for (int gq = 0; gq < ng; ++gq) {
+    const int4 w = *reinterpret_cast<const int4*>(k + 4 * gq);
+    const int wv[4] = {w.x, w.y, w.z, w.w};
+    uint32_t a[CS];
+#pragma unroll
+    for (int j = 0; j < CS; ++j) {
+      const uint32_t d1 = d[CS * gq + j + 1];
+      a[j] = __builtin_amdgcn_alignbyte(d1, d0, sh);
+      d0 = d1;
+    }
+#pragma unroll
+    for (int j = 0; j < 4 * CS; ++j) acc[j % CS] += mul24(byte_of(a[j >> 2], j & 3), wv[j / CS]);
+  }
+}
 
 template <typename OUT>
 __global__ __launch_bounds__(FT_THREADS) void frames_transform_kernel(FrameGeom g, const uint8_t* __restrict__ src,
@@ -44,22 +73,41 @@ __global__ __launch_bounds__(FT_THREADS) void frames_transform_kernel(FrameGeom 
                                                                       const float* __restrict__ stdv,
                                                                       OUT* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  uint8_t* raw = lds;                               // source rows (RGB), starting `mis` bytes in
-  uint8_t* lum = lds + g.raw_bytes;                 // gray only: luma of the source rows
-  uint8_t* tmp = lds + g.raw_bytes + g.lum_bytes;   // horizontally reduced rows [nrows][wd][co]
+  uint8_t* raw = lds;                                        // source rows (RGB), starting `mis` bytes in
+  uint8_t* lum = raw + g.raw_bytes;                          // gray only: luma of the source rows
+  uint8_t* tmp = lum + g.lum_bytes;                          // horizontally reduced rows [nrows][co][wdp]
+  int* xkL = reinterpret_cast<int*>(tmp + g.tmp_bytes);      // [wd][kpx]
+  int* xbL = xkL + g.wd * g.kpx;                             // [wdp] first source column of every window
+  int* ykL = xbL + g.wdp;                                    // [ty][ksy]
+  int* ybL = ykL + g.ty * g.ksy;                             // [ty] first tile row of every window
+  float* lut = reinterpret_cast<float*>(ybL + ((g.ty + 3) & ~3));  // [co][256] normalised value of a byte
 
   const int tid = threadIdx.x;
   const int n = blockIdx.y;
   const int y0 = blockIdx.x * g.ty;
   const int y1 = min(y0 + g.ty, g.hd);
 
-  // source rows [r0, r0 + nrows) feed the output rows [y0, y1); tables are clamped so that a table of another
-  // geometry can produce wrong pixels but never an access outside the frame
+  // source rows [r0, r0 + nrows) feed the output rows [y0, y1); everything read from the tables is clamped, so
+  // that tables of another geometry give wrong pixels but never an access outside the frame or the tile
   int r0 = yb[2 * y0];
   int rend = yb[2 * (y1 - 1)] + yb[2 * (y1 - 1) + 1];
   r0 = max(0, min(r0, g.hs - 1));
   rend = max(r0 + 1, min(rend, g.hs));
   const int nrows = min(rend - r0, g.cap_rows);
+
+  // --- tables ---
+  for (int i = tid; i < g.wd * g.kpx; i += FT_THREADS) {
+    const int x = i / g.kpx, t = i - x * g.kpx;
+    xkL[i] = t < g.ksx ? xk[x * g.ksx + t] : 0;
+  }
+  for (int i = tid; i < g.wd; i += FT_THREADS) xbL[i] = max(0, min(xb[2 * i], g.ws - 1));
+  for (int i = tid; i < (y1 - y0) * g.ksy; i += FT_THREADS) ykL[i] = yk[y0 * g.ksy + i];
+  for (int i = tid; i < y1 - y0; i += FT_THREADS) ybL[i] = max(0, min(yb[2 * (y0 + i)] - r0, nrows - 1));
+  for (int i = tid; i < g.co * 256; i += FT_THREADS) {
+    const int c = i >> 8;
+    const float f = (float)(i & 255) / 255.0f;  // ToTensor
+    lut[i] = (f - mean[c]) / stdv[c];            // Normalize
+  }
 
   // --- stage the source rows: one contiguous byte range, 16-byte loads from a 16-byte aligned start ---
   const size_t row_bytes = (size_t)g.ws * 3;
@@ -78,55 +126,88 @@ __global__ __launch_bounds__(FT_THREADS) void frames_transform_kernel(FrameGeom 
   }
   __syncthreads();
 
-  const uint8_t* hsrc = raw + mis;  // [nrows][ws][3]
-  int cs = 3;
-  if (g.gray) {
-    const int npix = nrows * g.ws;
-    for (int i = tid; i < npix; i += FT_THREADS) {
-      const uint8_t* p = hsrc + i * 3;
-      lum[i] = (uint8_t)((p[0] * 19595 + p[1] * 38470 + p[2] * 7471 + 0x8000) >> 16);
+  if (g.gray) {  // four pixels (12 source bytes) per step
+    const int npix4 = (nrows * g.ws + 3) >> 2;
+    const uint32_t* d = reinterpret_cast<const uint32_t*>(raw + (mis & ~3));
+    const uint32_t sh = (uint32_t)(mis & 3);
+    for (int i = tid; i < npix4; i += FT_THREADS) {
+      const uint32_t d0 = d[3 * i], d1 = d[3 * i + 1], d2 = d[3 * i + 2], d3 = d[3 * i + 3];
+      const uint32_t a[3] = {__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
+                             __builtin_amdgcn_alignbyte(d3, d2, sh)};
+      uint32_t o = 0;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int r = byte_of(a[(3 * p) >> 2], (3 * p) & 3), gg = byte_of(a[(3 * p + 1) >> 2], (3 * p + 1) & 3),
+                  b = byte_of(a[(3 * p + 2) >> 2], (3 * p + 2) & 3);
+        o |= (uint32_t)((r * 19595 + gg * 38470 + b * 7471 + 0x8000) >> 16) << (8 * p);
+      }
+      reinterpret_cast<uint32_t*>(lum)[i] = o;
     }
     __syncthreads();
-    hsrc = lum;
-    cs = 1;
   }
 
-  // --- horizontal pass into tmp ---
-  const int wdco = g.wd * g.co;
-  const int hitems = nrows * wdco;
-  for (int i = tid; i < hitems; i += FT_THREADS) {
-    int r, rem, x, c;
-    fd_divmod(i, g.f_wdco, r, rem);
-    fd_divmod(rem, g.f_co, x, c);
-    int cnt = min(min(xb[2 * x + 1], g.ksx), g.ws);
-    int x0 = max(0, min(xb[2 * x], g.ws - cnt));
-    const int* k = xk + x * g.ksx;
-    const uint8_t* p = hsrc + ((size_t)r * g.ws + x0) * cs + c;
-    int acc = 1 << (PREC - 1);
-    for (int t = 0; t < cnt; ++t) acc += (int)p[t * cs] * k[t];
-    tmp[i] = (uint8_t)clip8(acc >> PREC);
+  // --- horizontal pass into tmp (planar per channel, so that the vertical pass reads four columns per dword) ---
+  {
+    const int ng = g.kpx >> 2;
+    const int hitems = nrows * g.wd;
+    for (int i = tid; i < hitems; i += FT_THREADS) {
+      int r, x;
+      fd_divmod(i, g.f_wd, r, x);
+      const int x0 = xbL[x];
+      const int* k = xkL + x * g.kpx;
+      if (g.gray) {
+        int acc[1];
+        hpass_pixel<1>(lum, r * g.ws + x0, k, ng, acc);
+        tmp[r * g.wdp + x] = (uint8_t)clip8(acc[0] >> PREC);
+      } else {
+        int acc[3];
+        hpass_pixel<3>(raw, mis + (r * g.ws + x0) * 3, k, ng, acc);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) tmp[(r * 3 + c) * g.wdp + x] = (uint8_t)clip8(acc[c] >> PREC);
+      }
+    }
   }
   __syncthreads();
 
-  // --- vertical pass, ToTensor, Normalize, flip; x fastest so that stores coalesce ---
+  // --- vertical pass, ToTensor + Normalize through the table, flip; four columns per thread ---
   const bool fl = flip != nullptr && flip[n] != 0;
-  const int vitems = (y1 - y0) * wdco;
+  const int w4 = g.wdp >> 2;
+  const int vitems = (y1 - y0) * g.co * w4;
+  const bool vec_ok = (g.wd & 3) == 0;
   for (int i = tid; i < vitems; i += FT_THREADS) {
-    int t2, x, yy, c;
-    fd_divmod(i, g.f_wd, t2, x);
+    int t2, x4, yy, c;
+    fd_divmod(i, g.f_w4, t2, x4);
     fd_divmod(t2, g.f_co, yy, c);
-    const int y = y0 + yy;
-    int q0 = max(0, min(yb[2 * y] - r0, nrows - 1));
-    int cnt = min(min(yb[2 * y + 1], g.ksy), nrows - q0);
-    const int* k = yk + y * g.ksy;
-    const uint8_t* p = tmp + ((size_t)q0 * g.wd + x) * g.co + c;
-    int acc = 1 << (PREC - 1);
-    for (int t = 0; t < cnt; ++t) acc += (int)p[t * wdco] * k[t];
-    const int v = clip8(acc >> PREC);
-    float f = (float)v / 255.0f;
-    f = (f - mean[c]) / stdv[c];
-    const int xo = fl ? g.wd - 1 - x : x;
-    out[(((size_t)n * g.co + c) * g.hd + y) * g.wd + xo] = from_f32<OUT>(f);
+    const int q0 = ybL[yy];
+    const int* k = ykL + yy * g.ksy;
+    int acc[4] = {1 << (PREC - 1), 1 << (PREC - 1), 1 << (PREC - 1), 1 << (PREC - 1)};
+    for (int t = 0; t < g.ksy; ++t) {
+      const int row = min(q0 + t, nrows - 1);
+      const uint32_t d = *reinterpret_cast<const uint32_t*>(tmp + (row * g.co + c) * g.wdp + 4 * x4);
+      const int w = k[t];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] += mul24(byte_of(d, j), w);
+    }
+    float f[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f[j] = lut[c * 256 + clip8(acc[j] >> PREC)];
+    OUT* orow = out + (((size_t)n * g.co + c) * g.hd + (y0 + yy)) * g.wd;
+    const int x = 4 * x4;
+    if (vec_ok) {
+      OUT v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = from_f32<OUT>(fl ? f[3 - j] : f[j]);
+      OUT* dst = orow + (fl ? g.wd - 4 - x : x);
+      if constexpr (sizeof(OUT) == 4) {
+        *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(v);
+      } else {
+        *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(v);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (x + j < g.wd) orow[fl ? g.wd - 1 - (x + j) : x + j] = from_f32<OUT>(f[j]);
+    }
   }
 }
 
@@ -197,7 +278,8 @@ int vc_frames_transform(const void* frames, int n, int hs, int ws, int gray, int
                vc_resample_ksize(ws, wd), vc_resample_ksize(hs, hd));
   if (n == 0) return VC_OK;
   VC_CHECK_ARG(frames && xbounds && xk && ybounds && yk && mean && stdv && out, "vc_frames_transform: null pointer");
-  VC_CHECK_ARG((reinterpret_cast<uintptr_t>(frames) & 15) == 0, "vc_frames_transform: frames must be 16-byte aligned");
+  VC_CHECK_ARG((reinterpret_cast<uintptr_t>(frames) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0,
+               "vc_frames_transform: frames and out must be 16-byte aligned");
   VC_CHECK_SHAPE(n <= 65535, "vc_frames_transform: at most 65535 frames per call (got %d)", n);
   VC_CHECK_SHAPE((int64_t)hs * ws * 3 < (1ll << 31) && (int64_t)hd * wd * 3 < (1ll << 31),
                  "vc_frames_transform: frame too large");
@@ -208,30 +290,34 @@ int vc_frames_transform(const void* frames, int n, int hs, int ws, int gray, int
   g.gray = gray ? 1 : 0;
   g.co = gray ? 1 : 3;
   g.ksx = ksx; g.ksy = ksy;
+  g.kpx = (ksx + 3) & ~3;
+  g.wdp = (wd + 3) & ~3;
   int lds = 0;
-  // the largest block of rows whose tiles stay small enough for several workgroups per CU; smaller blocks for
-  // wide or strongly reduced frames, down to one row
+  // the largest block of rows whose tiles leave room for several workgroups per CU; smaller blocks for wide or
+  // strongly reduced frames, down to one row
   const int tys[] = {16, 8, 4, 2, 1};
   for (int pass = 0; pass < 2 && lds == 0; ++pass) {
-    const int limit = pass == 0 ? 40 * 1024 : FT_MAX_LDS;
+    const int limit = pass == 0 ? 52 * 1024 : FT_MAX_LDS;
     for (int ty : tys) {
       const int cap = rows_cap(hs, hd, ty);
-      const int raw = ((cap * ws * 3 + 15 + 15) & ~15) + 16;
-      const int lum = gray ? ((cap * ws + 15) & ~15) : 0;
-      const int tmp = (cap * wd * g.co + 15) & ~15;
-      if (raw + lum + tmp <= limit) {
-        g.ty = ty; g.cap_rows = cap; g.raw_bytes = raw; g.lum_bytes = lum;
-        lds = raw + lum + tmp;
+      // the passes read up to kpx taps and one dword beyond a window: slack behind the row data
+      const int slack = ((g.kpx * 3 + 8 + 15) & ~15) + 16;
+      const int raw = ((cap * ws * 3 + 15 + 15) & ~15) + slack;
+      const int lum = gray ? ((cap * ws + 15) & ~15) + slack : 0;
+      const int tmp = (cap * g.co * g.wdp + 15) & ~15;
+      const int tables = 4 * (wd * g.kpx + g.wdp + ty * ksy + ((ty + 3) & ~3) + g.co * 256);
+      if (raw + lum + tmp + tables <= limit) {
+        g.ty = ty; g.cap_rows = cap; g.raw_bytes = raw; g.lum_bytes = lum; g.tmp_bytes = tmp;
+        lds = raw + lum + tmp + tables;
         break;
       }
     }
   }
   VC_CHECK_SHAPE(lds > 0, "vc_frames_transform: %d x %d -> %d x %d needs more than %d bytes of LDS per row block",
                  hs, ws, hd, wd, FT_MAX_LDS);
-  g.f_wdco = make_fastdiv(wd * g.co);
-  g.f_co = make_fastdiv(g.co);
   g.f_wd = make_fastdiv(wd);
-  g.f_ws = make_fastdiv(ws);
+  g.f_w4 = make_fastdiv(g.wdp >> 2);
+  g.f_co = make_fastdiv(g.co);
 
   dim3 grid(ceil_div(hd, g.ty), n);
   const uint8_t* s = static_cast<const uint8_t*>(frames);
