@@ -37,6 +37,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X
+HBM_PEAK_GBS = 8000.0           # HBM3E peak, MI355X
 
 
 def build_workload(args, M, S, oracle=False):
@@ -268,6 +269,10 @@ def main():
     if "conv_fwd" in fam and fam["conv_fwd"][1] > 0:
         fl, tm, n, nb = fam["conv_fwd"]
         ach = fl / tm / 1e12
+        # the family mixes MFMA-bound 3x3 layers with HBM-bound 1x1 / stem layers: the time each launch would take
+        # at whichever of the two peaks binds it, summed, against the measured time of the family
+        floor_s = sum(max(f_ / (MFMA_BF16_PEAK_TFLOPS * 1e12), b_ / (HBM_PEAK_GBS * 1e9))
+                      for t_, f_, _, _, b_ in prof if t_ == "conv_fwd")
         # HBM bytes per launch of the same kernel family from the PMC passes (tools/pmc_bench.sh, separate runs of
         # this command with --no-graph; FETCH_SIZE doubled as gfx950 requires) -- None if they were never collected
         traffic, traffic_src, traffic_step = None, None, None
@@ -281,7 +286,10 @@ def main():
                 traffic_src = "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
         roof = {"bound": "mfma", "kernel": "igemm_nt_persist_kernel<0,*> (forward implicit-GEMM conv/linear)",
                 "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes per launch",
+                "frac": ach / MFMA_BF16_PEAK_TFLOPS, "frac_of_per_launch_roofline": floor_s / tm,
+                "per_launch_roofline": "sum over launches of max(flops / 2.5 PFLOP/s, algorithmic bytes / 8 TB/s) / "
+                                       "measured time of the family",
+                "traffic": traffic, "traffic_unit": "bytes per launch",
                 "traffic_source": traffic_src, "traffic_bytes_per_step": traffic_step,
                 "algorithmic_bytes_per_launch": nb / n, "algorithmic_bytes_per_step": nb / prof_steps,
                 "launches": n, "avg_launch_ms": tm / n * 1e3, "avg_launch_gflop": fl / n / 1e9,
