@@ -274,12 +274,23 @@ int vc_counter_add(int64_t* counter, int64_t inc, vc_stream_t stream);
  * C = 1 if gray (convert('L') before the resize, Dataset_3DCNN) else 3: Resize([hd, wd]) -> flip of the frames
  * with flip[i] != 0 (nullable; one flag per frame, the reference draws RandomHorizontalFlip per frame) -> ToTensor
  * -> Normalize(mean[C], std[C]).  Integer-exact with Pillow up to the uint8 frame, fp32 output bit-identical to
- * the host chain.  RandomCrop(size) after Resize to the same size is the identity; ColorJitter is not provided. */
+ * the host chain.  RandomCrop(size) after Resize to the same size is the identity; ColorJitter: vc_frames_jitter. */
 int vc_resample_ksize(int in_size, int out_size);
 int vc_resample_coeffs(int in_size, int out_size, int* bounds, int* kk);
 int vc_frames_transform(const void* frames, int n, int hs, int ws, int gray, int hd, int wd, const int* xbounds,
                         const int* xk, int ksx, const int* ybounds, const int* yk, int ksy, const void* flip,
                         const float* mean, const float* stdv, void* out, int out_dtype, vc_stream_t stream);
+/* ColorJitter(brightness, contrast, saturation, hue) of train.py:377-378 between the flip and ToTensor.
+ * vc_frames_transform with out_dtype 2 stops after the flip and writes the uint8 frame, planar [n][C][hd][wd]
+ * (mean / stdv unused).  vc_frames_jitter then applies to every frame i of planes_u8 [n][3][h][w] (overwritten)
+ * the operations order[4 i .. 4 i + 3] (0 brightness, 1 contrast, 2 saturation, 3 hue, >= 4 nothing; torchvision
+ * draws a permutation per call, a second contrast entry is ignored) with the factors factors[3 i .. 3 i + 2]
+ * (brightness, contrast, saturation) and hue_shift[i] = (uint8)(hue_factor * 255), followed by ToTensor and
+ * Normalize into out [n][3][h][w] of out_dtype 0 / 1.  Byte-identical to torchvision's PIL path (ImageEnhance
+ * blends in float32, Pillow's RGB <-> HSV conversions). */
+int vc_frames_jitter(void* planes_u8, int n, int h, int w, const void* order, const float* factors,
+                     const void* hue_shift, const float* mean, const float* stdv, void* out, int out_dtype,
+                     vc_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--src", default="256x340")
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--gray", action="store_true")
+    ap.add_argument("--jitter", action="store_true", help="ColorJitter(0.2, 0.2, 0.2, 0.1) between flip and ToTensor")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--cpu-frames", type=int, default=256)
@@ -59,14 +60,17 @@ def main():
     frames = torch.from_numpy(host).to(dev)
     flip = torch.from_numpy((rng.random(a.frames) < 0.5).astype(np.uint8)).to(dev)
     tf = FR.FrameTransform(a.size, mean, std, gray=a.gray, device=dev, dtype=dt)
-    out = tf(frames, flip)
+    jp = None
+    if a.jitter:  # parameters drawn once and resident, so that the timed region holds the two kernels only
+        jp = tuple(t.to(dev) for t in FR.draw_jitter(a.frames, 0.2, 0.2, 0.2, 0.1, generator=torch.Generator().manual_seed(0)))
+    out = tf(frames, flip, jitter_params=jp)
     for _ in range(5):
-        tf(frames, flip, out=out)
+        tf(frames, flip, out=out, jitter_params=jp)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()  # the kernel is launched on torch's current stream, which is the one these events time
     for _ in range(a.iters):
-        tf(frames, flip, out=out)
+        tf(frames, flip, out=out, jitter_params=jp)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.iters
@@ -87,11 +91,15 @@ def main():
     line = {"metric": "frames_transformed_per_sec", "value": a.frames / (ms * 1e-3), "unit": "frames/s", "n_gpus": 1,
             "ms_per_call": ms, "dtype": "u8 -> " + a.dtype, "data": "synthetic",
             "config": {"workload": f"{a.frames} RGB frames {hs}x{ws} -> {c}x{a.size}x{a.size}"
-                                   f"{' (luma)' if a.gray else ''}, resize + flip + normalise"},
+                                   f"{' (luma)' if a.gray else ''}, resize + flip{' + ColorJitter' if a.jitter else ''} + normalise"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": None,
                          "algorithmic_bytes_per_frame": bytes_per_frame},
             "h2d_ms_raw_frames": h2d_ms, "with_h2d_frames_per_sec": a.frames / ((ms + h2d_ms) * 1e-3)}
+    if a.jitter:
+        line["cpu_baseline"] = None  # the host chain of this tool has no ColorJitter (torchvision is absent)
+        print(json.dumps(line))
+        return
     try:
         torch.set_num_threads(1)
         n = min(a.cpu_frames, a.frames)

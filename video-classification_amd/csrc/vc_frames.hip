@@ -14,6 +14,11 @@
 
 #include "vc_common.h"
 
+// every floating-point step below has to round exactly as the host C code it restates: no fused multiply-add
+#pragma clang fp contract(off)
+
+#define VC_U8 2  // vc_frames_transform only: planar uint8 output, before ToTensor / Normalize
+
 namespace {
 
 constexpr int PREC = 22;  // 32 - 8 - 2, Pillow's PRECISION_BITS
@@ -103,10 +108,12 @@ __global__ __launch_bounds__(FT_THREADS) void frames_transform_kernel(FrameGeom 
   for (int i = tid; i < g.wd; i += FT_THREADS) xbL[i] = max(0, min(xb[2 * i], g.ws - 1));
   for (int i = tid; i < (y1 - y0) * g.ksy; i += FT_THREADS) ykL[i] = yk[y0 * g.ksy + i];
   for (int i = tid; i < y1 - y0; i += FT_THREADS) ybL[i] = max(0, min(yb[2 * (y0 + i)] - r0, nrows - 1));
-  for (int i = tid; i < g.co * 256; i += FT_THREADS) {
-    const int c = i >> 8;
-    const float f = (float)(i & 255) / 255.0f;  // ToTensor
-    lut[i] = (f - mean[c]) / stdv[c];            // Normalize
+  if constexpr (sizeof(OUT) != 1) {
+    for (int i = tid; i < g.co * 256; i += FT_THREADS) {
+      const int c = i >> 8;
+      const float f = (float)(i & 255) / 255.0f;  // ToTensor
+      lut[i] = (f - mean[c]) / stdv[c];            // Normalize
+    }
   }
 
   // --- stage the source rows: one contiguous byte range, 16-byte loads from a 16-byte aligned start ---
@@ -188,26 +195,211 @@ __global__ __launch_bounds__(FT_THREADS) void frames_transform_kernel(FrameGeom 
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[j] += mul24(byte_of(d, j), w);
     }
-    float f[4];
+    int bv[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) f[j] = lut[c * 256 + clip8(acc[j] >> PREC)];
+    for (int j = 0; j < 4; ++j) bv[j] = clip8(acc[j] >> PREC);
     OUT* orow = out + (((size_t)n * g.co + c) * g.hd + (y0 + yy)) * g.wd;
     const int x = 4 * x4;
-    if (vec_ok) {
-      OUT v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = from_f32<OUT>(fl ? f[3 - j] : f[j]);
-      OUT* dst = orow + (fl ? g.wd - 4 - x : x);
-      if constexpr (sizeof(OUT) == 4) {
-        *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(v);
+    if constexpr (sizeof(OUT) == 1) {  // planar uint8: the resized (and flipped) frame itself
+      if (vec_ok) {
+        const uint32_t w = fl ? (uint32_t)(bv[3] | (bv[2] << 8) | (bv[1] << 16) | (bv[0] << 24))
+                              : (uint32_t)(bv[0] | (bv[1] << 8) | (bv[2] << 16) | (bv[3] << 24));
+        *reinterpret_cast<uint32_t*>(orow + (fl ? g.wd - 4 - x : x)) = w;
       } else {
-        *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (x + j < g.wd) orow[fl ? g.wd - 1 - (x + j) : x + j] = (OUT)bv[j];
       }
     } else {
+      float f[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (x + j < g.wd) orow[fl ? g.wd - 1 - (x + j) : x + j] = from_f32<OUT>(f[j]);
+      for (int j = 0; j < 4; ++j) f[j] = lut[c * 256 + bv[j]];
+      if (vec_ok) {
+        OUT v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = from_f32<OUT>(fl ? f[3 - j] : f[j]);
+        OUT* dst = orow + (fl ? g.wd - 4 - x : x);
+        if constexpr (sizeof(OUT) == 4) {
+          *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(v);
+        } else {
+          *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(v);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (x + j < g.wd) orow[fl ? g.wd - 1 - (x + j) : x + j] = from_f32<OUT>(f[j]);
+      }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// ColorJitter on the resized uint8 frame (planar), then ToTensor + Normalize.  torchvision applies brightness,
+// contrast, saturation and hue to a PIL image in an order drawn per call; each is Pillow byte arithmetic:
+// Image.blend in float32 against black / the frame's rounded mean luma / the pixel's luma, and an RGB -> HSV -> RGB
+// round trip with the uint8 hue shifted (wrap-around).  The float and double steps below follow Pillow's C code
+// operation by operation, so the bytes are identical.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int JT_THREADS = 1024;
+
+__device__ __forceinline__ int luma_of(int r, int g, int b) {
+  return (r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16;
+}
+
+// Image.blend(im1, im2, alpha): (UINT8)(in1 + alpha * (in2 - in1)) inside [0, 1], clipped outside
+__device__ __forceinline__ int blend_byte(int in1, int in2, float alpha, bool inside) {
+  const float s = (float)in1 + alpha * (float)(in2 - in1);
+  if (inside) return (int)s;
+  return s <= 0.f ? 0 : (s >= 255.f ? 255 : (int)s);
+}
+
+__device__ __forceinline__ void rgb_to_hsv(int r, int g, int b, int& uh, int& us, int& uv) {
+  const int maxc = max(r, max(g, b)), minc = min(r, min(g, b));
+  uv = maxc;
+  if (minc == maxc) {
+    uh = 0;
+    us = 0;
+    return;
+  }
+  const float cr = (float)(maxc - minc);
+  const float s = cr / (float)maxc;
+  const float rc = (float)(maxc - r) / cr, gc = (float)(maxc - g) / cr, bc = (float)(maxc - b) / cr;
+  float h;
+  if (r == maxc) h = bc - gc;
+  else if (g == maxc) h = (float)(2.0 + (double)rc - (double)bc);
+  else h = (float)(4.0 + (double)gc - (double)rc);
+  h = (float)fmod((double)h / 6.0 + 1.0, 1.0);
+  uh = clip8((int)((double)h * 255.0));
+  us = clip8((int)((double)s * 255.0));
+}
+
+__device__ __forceinline__ int round_half_away(double z) { return (int)(z >= 0.0 ? floor(z + 0.5) : ceil(z - 0.5)); }
+
+__device__ __forceinline__ void hsv_to_rgb(int h, int s, int v, int& r, int& g, int& b) {
+  if (s == 0) {
+    r = g = b = v;
+    return;
+  }
+  const double hh = (double)(float)h * 6.0 / 255.0;
+  const int i = (int)floor(hh);
+  const double f = (double)(float)(hh - (double)(float)i);
+  const double fs = (double)(float)((double)(float)s / 255.0);
+  const double vf = (double)(float)v;
+  const int p = clip8(round_half_away(vf * (1.0 - fs)));
+  const int q = clip8(round_half_away(vf * (1.0 - fs * f)));
+  const int t = clip8(round_half_away(vf * (1.0 - fs * (1.0 - f))));
+  switch (i % 6) {
+    case 0: r = v; g = t; b = p; break;
+    case 1: r = q; g = v; b = p; break;
+    case 2: r = p; g = v; b = t; break;
+    case 3: r = p; g = q; b = v; break;
+    case 4: r = t; g = p; b = v; break;
+    default: r = v; g = p; b = q; break;
+  }
+}
+
+struct JitterParams {
+  float fb, fc, fs;
+  bool in_b, in_c, in_s;
+  int shift;
+};
+
+// one operation of the chain on one pixel; `mean` is the frame's rounded mean luma (contrast only)
+__device__ __forceinline__ void jitter_op(int op, const JitterParams& jp, int mean, int& r, int& g, int& b) {
+  if (op == 0) {
+    r = blend_byte(0, r, jp.fb, jp.in_b);
+    g = blend_byte(0, g, jp.fb, jp.in_b);
+    b = blend_byte(0, b, jp.fb, jp.in_b);
+  } else if (op == 1) {
+    r = blend_byte(mean, r, jp.fc, jp.in_c);
+    g = blend_byte(mean, g, jp.fc, jp.in_c);
+    b = blend_byte(mean, b, jp.fc, jp.in_c);
+  } else if (op == 2) {
+    const int l = luma_of(r, g, b);
+    r = blend_byte(l, r, jp.fs, jp.in_s);
+    g = blend_byte(l, g, jp.fs, jp.in_s);
+    b = blend_byte(l, b, jp.fs, jp.in_s);
+  } else if (op == 3) {
+    int h, s, v;
+    rgb_to_hsv(r, g, b, h, s, v);
+    hsv_to_rgb((h + jp.shift) & 255, s, v, r, g, b);
+  }
+}
+
+// One workgroup per frame.  Every thread owns the pixels tid, tid + 1024, ...; the operations ahead of the
+// contrast step are applied in a first sweep that also sums the luma (contrast blends against the mean luma of the
+// frame as it is at that point of the chain), the rest in a second sweep that ends in the normalised output.
+template <typename OUT>
+__global__ __launch_bounds__(JT_THREADS) void frames_jitter_kernel(uint8_t* __restrict__ planes, int hw,
+                                                                   const uint8_t* __restrict__ order,
+                                                                   const float* __restrict__ factors,
+                                                                   const uint8_t* __restrict__ hue_shift,
+                                                                   const float* __restrict__ mean,
+                                                                   const float* __restrict__ stdv,
+                                                                   OUT* __restrict__ out) {
+  __shared__ float lut[3 * 256];
+  __shared__ int red[JT_THREADS / 64];
+  const int tid = threadIdx.x, n = blockIdx.x;
+  uint8_t* P = planes + (size_t)n * 3 * hw;
+  OUT* O = out + (size_t)n * 3 * hw;
+
+  int ops[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) ops[k] = order[4 * n + k];
+  JitterParams jp;
+  jp.fb = factors[3 * n];
+  jp.fc = factors[3 * n + 1];
+  jp.fs = factors[3 * n + 2];
+  jp.in_b = jp.fb >= 0.f && jp.fb <= 1.f;
+  jp.in_c = jp.fc >= 0.f && jp.fc <= 1.f;
+  jp.in_s = jp.fs >= 0.f && jp.fs <= 1.f;
+  jp.shift = hue_shift[n];
+  int cpos = 4;  // position of the (first) contrast step; a second one is ignored
+#pragma unroll
+  for (int k = 3; k >= 0; --k)
+    if (ops[k] == 1) cpos = k;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (k > cpos && ops[k] == 1) ops[k] = 255;
+
+  for (int i = tid; i < 3 * 256; i += JT_THREADS) {
+    const int c = i >> 8;
+    const float f = (float)(i & 255) / 255.0f;
+    lut[i] = (f - mean[c]) / stdv[c];
+  }
+
+  int mean_l = 0;
+  if (cpos < 4) {
+    int sum = 0;
+    for (int i = tid; i < hw; i += JT_THREADS) {
+      int r = P[i], g = P[hw + i], b = P[2 * hw + i];
+      if (cpos > 0) {
+        for (int k = 0; k < cpos; ++k) jitter_op(ops[k], jp, 0, r, g, b);
+        P[i] = (uint8_t)r;
+        P[hw + i] = (uint8_t)g;
+        P[2 * hw + i] = (uint8_t)b;
+      }
+      sum += luma_of(r, g, b);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = sum;
+    __syncthreads();
+    long long tot = 0;
+    for (int w = 0; w < JT_THREADS / 64; ++w) tot += red[w];
+    // int(mean + 0.5) of ImageStat's mean = sum / count
+    mean_l = (int)((2 * tot + hw) / (2 * (long long)hw));
+  } else {
+    __syncthreads();  // the table
+  }
+
+  const int k0 = cpos < 4 ? cpos : 0;
+  for (int i = tid; i < hw; i += JT_THREADS) {
+    int r = P[i], g = P[hw + i], b = P[2 * hw + i];
+    for (int k = k0; k < 4; ++k) jitter_op(ops[k], jp, mean_l, r, g, b);
+    O[i] = from_f32<OUT>(lut[r]);
+    O[hw + i] = from_f32<OUT>(lut[256 + g]);
+    O[2 * hw + i] = from_f32<OUT>(lut[512 + b]);
   }
 }
 
@@ -272,12 +464,14 @@ int vc_frames_transform(const void* frames, int n, int hs, int ws, int gray, int
                         const int* xk, int ksx, const int* ybounds, const int* yk, int ksy, const void* flip,
                         const float* mean, const float* stdv, void* out, int out_dtype, hipStream_t stream) {
   VC_CHECK_SHAPE(n >= 0 && hs >= 1 && ws >= 1 && hd >= 1 && wd >= 1, "vc_frames_transform: bad extents");
-  VC_CHECK_ARG(out_dtype == VC_F32 || out_dtype == VC_BF16, "vc_frames_transform: dtype %d", out_dtype);
+  VC_CHECK_ARG(out_dtype == VC_F32 || out_dtype == VC_BF16 || out_dtype == VC_U8, "vc_frames_transform: dtype %d",
+               out_dtype);
   VC_CHECK_ARG(ksx == vc_resample_ksize(ws, wd) && ksy == vc_resample_ksize(hs, hd),
                "vc_frames_transform: weight tables of another geometry (ksize %d/%d, expected %d/%d)", ksx, ksy,
                vc_resample_ksize(ws, wd), vc_resample_ksize(hs, hd));
   if (n == 0) return VC_OK;
-  VC_CHECK_ARG(frames && xbounds && xk && ybounds && yk && mean && stdv && out, "vc_frames_transform: null pointer");
+  VC_CHECK_ARG(frames && xbounds && xk && ybounds && yk && out && (out_dtype == VC_U8 || (mean && stdv)),
+               "vc_frames_transform: null pointer");
   VC_CHECK_ARG((reinterpret_cast<uintptr_t>(frames) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0,
                "vc_frames_transform: frames and out must be 16-byte aligned");
   VC_CHECK_SHAPE(n <= 65535, "vc_frames_transform: at most 65535 frames per call (got %d)", n);
@@ -322,28 +516,42 @@ int vc_frames_transform(const void* frames, int n, int hs, int ws, int gray, int
   dim3 grid(ceil_div(hd, g.ty), n);
   const uint8_t* s = static_cast<const uint8_t*>(frames);
   const uint8_t* fl = static_cast<const uint8_t*>(flip);
-  if (out_dtype == VC_F32) {
-    auto kern = frames_transform_kernel<float>;
+  auto launch = [&](auto kern, auto* o) -> int {
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
             hipSuccess) {
       vc_set_error("vc_frames_transform: cannot reserve %d bytes of LDS", lds);
       return VC_ERR_HIP;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(FT_THREADS), lds, stream, g, s, xbounds, xk, ybounds, yk, fl, mean, stdv,
-                       static_cast<float*>(out));
-  } else {
-    auto kern = frames_transform_kernel<bf16>;
-    if (lds > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
-            hipSuccess) {
-      vc_set_error("vc_frames_transform: cannot reserve %d bytes of LDS", lds);
-      return VC_ERR_HIP;
-    }
-    hipLaunchKernelGGL(kern, grid, dim3(FT_THREADS), lds, stream, g, s, xbounds, xk, ybounds, yk, fl, mean, stdv,
-                       static_cast<bf16*>(out));
-  }
+    hipLaunchKernelGGL(kern, grid, dim3(FT_THREADS), lds, stream, g, s, xbounds, xk, ybounds, yk, fl, mean, stdv, o);
+    return VC_OK;
+  };
+  int rc;
+  if (out_dtype == VC_F32) rc = launch(frames_transform_kernel<float>, static_cast<float*>(out));
+  else if (out_dtype == VC_BF16) rc = launch(frames_transform_kernel<bf16>, static_cast<bf16*>(out));
+  else rc = launch(frames_transform_kernel<uint8_t>, static_cast<uint8_t*>(out));
+  if (rc != VC_OK) return rc;
   VC_LAUNCH_CHECK("vc_frames_transform");
+  return VC_OK;
+}
+
+int vc_frames_jitter(void* planes_u8, int n, int h, int w, const void* order, const float* factors,
+                     const void* hue_shift, const float* mean, const float* stdv, void* out, int out_dtype,
+                     hipStream_t stream) {
+  VC_CHECK_SHAPE(n >= 0 && h >= 1 && w >= 1 && (int64_t)h * w * 3 < (1ll << 31), "vc_frames_jitter: bad extents");
+  VC_CHECK_ARG(out_dtype == VC_F32 || out_dtype == VC_BF16, "vc_frames_jitter: dtype %d", out_dtype);
+  if (n == 0) return VC_OK;
+  VC_CHECK_ARG(planes_u8 && order && factors && hue_shift && mean && stdv && out, "vc_frames_jitter: null pointer");
+  uint8_t* p = static_cast<uint8_t*>(planes_u8);
+  const uint8_t* ord = static_cast<const uint8_t*>(order);
+  const uint8_t* hs = static_cast<const uint8_t*>(hue_shift);
+  if (out_dtype == VC_F32)
+    hipLaunchKernelGGL(frames_jitter_kernel<float>, dim3(n), dim3(JT_THREADS), 0, stream, p, h * w, ord, factors, hs,
+                       mean, stdv, static_cast<float*>(out));
+  else
+    hipLaunchKernelGGL(frames_jitter_kernel<bf16>, dim3(n), dim3(JT_THREADS), 0, stream, p, h * w, ord, factors, hs,
+                       mean, stdv, static_cast<bf16*>(out));
+  VC_LAUNCH_CHECK("vc_frames_jitter");
   return VC_OK;
 }
 

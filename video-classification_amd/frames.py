@@ -23,6 +23,7 @@ from . import _lib as L
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)  # train.py:383-384
 IMAGENET_STD = (0.229, 0.224, 0.225)
+VC_U8 = 2  # vc_frames_transform: planar uint8 output (the resized, flipped frame before ToTensor)
 
 
 def resample_coeffs(in_size, out_size):
@@ -41,11 +42,50 @@ def resample_coeffs(in_size, out_size):
     return bounds, kk
 
 
-class FrameTransform:
-    """Resize([size_h, size_w]) -> per-frame flip -> ToTensor -> Normalize(mean, std) of uint8 RGB frames on the
-    device; ``gray=True`` converts to luma first (Dataset_3DCNN's ``convert('L')``) and yields one channel."""
+def _jitter_range(v, center=1.0, clip_zero=True):
+    """torchvision's ColorJitter argument check: a number v means [center - v, center + v] (brightness / contrast /
+    saturation clipped at 0), a pair is taken as it is; None or a zero-width range around the neutral value = off."""
+    if v is None:
+        return None
+    lo, hi = (center - float(v), center + float(v)) if not isinstance(v, (tuple, list)) else (float(v[0]), float(v[1]))
+    if clip_zero:
+        lo = max(lo, 0.0)
+    return None if lo == hi == center else (lo, hi)
 
-    def __init__(self, size, mean=IMAGENET_MEAN, std=IMAGENET_STD, gray=False, device="cuda", dtype=torch.float32):
+
+def draw_jitter(n, brightness=None, contrast=None, saturation=None, hue=None, generator=None):
+    """Per-frame ColorJitter parameters as torchvision draws them per call (a permutation of the four operations,
+    one uniform factor each): (order uint8 [n, 4], factors float32 [n, 3], hue_shift uint8 [n]) on the host.
+    An operation that is switched off gets code 255 in `order`."""
+    rb, rc, rs = _jitter_range(brightness), _jitter_range(contrast), _jitter_range(saturation)
+    rh = _jitter_range(hue, center=0.0, clip_zero=False)
+    order = torch.argsort(torch.rand(n, 4, generator=generator), dim=1).to(torch.uint8)
+    factors = torch.ones(n, 3, dtype=torch.float32)
+    for j, r in enumerate((rb, rc, rs)):
+        if r is None:
+            order[order == j] = 255
+        else:
+            factors[:, j] = r[0] + (r[1] - r[0]) * torch.rand(n, generator=generator)
+    shift = torch.zeros(n, dtype=torch.uint8)
+    if rh is None:
+        order[order == 3] = 255
+    else:
+        h = (rh[0] + (rh[1] - rh[0]) * torch.rand(n, generator=generator)).double()
+        shift = ((h * 255).trunc().to(torch.int64) & 255).to(torch.uint8)  # np.uint8(hue_factor * 255)
+    return order, factors, shift
+
+
+class FrameTransform:
+    """Resize([size_h, size_w]) -> per-frame flip -> [ColorJitter] -> ToTensor -> Normalize(mean, std) of uint8 RGB
+    frames on the device; ``gray=True`` converts to luma first (Dataset_3DCNN's ``convert('L')``) and yields one
+    channel.  ``jitter=dict(brightness=0.2, contrast=0.2, saturation=0.2, hue=0.1)`` (train.py:377-378) draws the
+    ColorJitter parameters per frame, as the reference's per-image transform call does."""
+
+    def __init__(self, size, mean=IMAGENET_MEAN, std=IMAGENET_STD, gray=False, device="cuda", dtype=torch.float32,
+                 jitter=None, generator=None):
+        if jitter and gray:
+            raise ValueError("ColorJitter applies to colour frames (the reference switches it off for Conv3D)")
+        self.jitter, self.generator = dict(jitter) if jitter else None, generator
         self.hd, self.wd = (size, size) if isinstance(size, int) else (int(size[0]), int(size[1]))
         self.gray = bool(gray)
         self.device = torch.device(device)
@@ -67,9 +107,10 @@ class FrameTransform:
             self._tables[key] = (dev(xb), dev(xk), xk.shape[1], dev(yb), dev(yk), yk.shape[1])
         return self._tables[key]
 
-    def __call__(self, frames, flip=None, out=None):
+    def __call__(self, frames, flip=None, out=None, jitter_params=None):
         """frames uint8 [..., H, W, 3] on the device -> [..., C, size_h, size_w]; flip: uint8 / bool, one entry
-        per frame (leading dimensions flattened), nonzero = mirror that frame."""
+        per frame (leading dimensions flattened), nonzero = mirror that frame; jitter_params: (order, factors,
+        hue_shift) as `draw_jitter` returns them, drawn here if the transform was built with ``jitter=``."""
         if frames.device.type != "cuda":
             raise RuntimeError("FrameTransform runs on the GPU (there is no CPU fallback); move the frames first")
         if frames.dtype != torch.uint8 or frames.dim() < 3 or frames.shape[-1] != 3:
@@ -88,9 +129,24 @@ class FrameTransform:
             if flip.numel() != n:
                 raise ValueError(f"flip needs one entry per frame ({n}), got {flip.numel()}")
         xb, xk, ksx, yb, yk, ksy = self._tab(hs, ws)
-        L.call("vc_frames_transform", L.ptr(frames), n, hs, ws, self.gray, self.hd, self.wd, L.ptr(xb), L.ptr(xk),
-               ksx, L.ptr(yb), L.ptr(yk), ksy, L.ptr(flip), L.ptr(self.mean), L.ptr(self.std), L.ptr(out),
-               L.dtype_code(out.dtype), L.stream())
+        if jitter_params is None and self.jitter:
+            jitter_params = draw_jitter(n, generator=self.generator, **self.jitter)
+        if jitter_params is None:
+            L.call("vc_frames_transform", L.ptr(frames), n, hs, ws, self.gray, self.hd, self.wd, L.ptr(xb), L.ptr(xk),
+                   ksx, L.ptr(yb), L.ptr(yk), ksy, L.ptr(flip), L.ptr(self.mean), L.ptr(self.std), L.ptr(out),
+                   L.dtype_code(out.dtype), L.stream())
+            return out
+        if self.gray:
+            raise ValueError("ColorJitter applies to colour frames")
+        order, factors, shift = (t.to(frames.device, non_blocking=True).contiguous() for t in jitter_params)
+        if order.numel() != 4 * n or factors.numel() != 3 * n or shift.numel() != n or order.dtype != torch.uint8 \
+                or factors.dtype != torch.float32 or shift.dtype != torch.uint8:
+            raise ValueError("jitter_params: order uint8 [n, 4], factors float32 [n, 3], hue_shift uint8 [n]")
+        planes = torch.empty(n, 3, self.hd, self.wd, device=frames.device, dtype=torch.uint8)
+        L.call("vc_frames_transform", L.ptr(frames), n, hs, ws, 0, self.hd, self.wd, L.ptr(xb), L.ptr(xk), ksx,
+               L.ptr(yb), L.ptr(yk), ksy, L.ptr(flip), L.ptr(None), L.ptr(None), L.ptr(planes), VC_U8, L.stream())
+        L.call("vc_frames_jitter", L.ptr(planes), n, self.hd, self.wd, L.ptr(order), L.ptr(factors), L.ptr(shift),
+               L.ptr(self.mean), L.ptr(self.std), L.ptr(out), L.dtype_code(out.dtype), L.stream())
         return out
 
 
