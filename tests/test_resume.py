@@ -124,7 +124,7 @@ def test_resume_hip_training_run(cuda, tmp_path):
         loss.backward()
         opt.step()
         sch.step()
-        return float(loss), opt.param_groups[0]["lr"]
+        return float(loss.detach()), opt.param_groups[0]["lr"]
 
     model, opt, sch = fresh()
     for i in range(3):

@@ -655,6 +655,10 @@ __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[
   }
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global access
+// (vmcnt(0)); where only LDS reads have to be over, this one lets the LDS-DMA stage in flight keep streaming.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Persistent form of the fast NT kernel: a block walks output tiles v, v + G, v + 2G, ... and its staging
 // pipeline runs straight through the tile boundaries, so the first k-tile of the next output tile is already
 // streaming in while the epilogue of the current one is written.  Layers with a short reduction (1x1
@@ -668,7 +672,8 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
                                                                    float* __restrict__ bn_partial,
                                                                    const bf16* __restrict__ tail_y = nullptr,
                                                                    const uint8_t* __restrict__ tail_bits = nullptr) {
-  __shared__ __attribute__((aligned(1024))) bf16 smem[2 * (BM + TN_) * BK];
+  constexpr int STAGE = (BM + TN_) * BK;
+  __shared__ __attribute__((aligned(1024))) bf16 smem[2 * STAGE];
   constexpr int WI = TN_ / 32;   // 16-channel tiles per wave
   constexpr int NWROW = TN_ / 32;  // weight rows staged per thread
 
@@ -770,20 +775,25 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
   const int aoff = (wm * 64 + l15) * BK, woff = BM * BK + (wn * (WI * 16) + l15) * BK;
 
   auto compute = [&](const bf16* tile) {
+    // all fragments of the k-tile are requested before the first product, so that one LDS round trip is exposed
+    // per k-tile instead of one per group of products
+    bf16x8 wf[2][WI], af[2][4];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int cc = ks ? c1 : c0;
-      bf16x8 wf[WI], af[4];
 #pragma unroll
-      for (int i = 0; i < WI; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(tile + woff + cc + i * 16 * BK);
+      for (int i = 0; i < WI; ++i) wf[ks][i] = *reinterpret_cast<const bf16x8*>(tile + woff + cc + i * 16 * BK);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(tile + aoff + cc + i * 16 * BK);
+      for (int i = 0; i < 4; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>(tile + aoff + cc + i * 16 * BK);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the requests ahead of the products
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < WI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
-    }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][i], af[ks][j], acc[i][j], 0, 0, 0);
   };
 
   // multiply state
@@ -794,8 +804,9 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
       if (out_f32) {
         nt_epilogue<MODE, WI>(g, acc, tile_m * BM, tile_n * TN_, wm, wn, lane, bias, out, relu, out_f32, beta);
       } else {
-        // the buffer that was just multiplied is free once every wave has finished reading it
-        __syncthreads();
+        // the buffer that was just multiplied is free once every wave has finished reading it (LDS reads only:
+        // the stage in flight keeps streaming while the tile is written out)
+        lds_barrier();
         nt_epilogue_lds<MODE, WI, EPI>(g, acc, tile_m * BM, tile_n * TN_, wm, wn, lane, bias,
                                         reinterpret_cast<bf16*>(out), relu, beta, cbuf + wave * (64 * WI * 16),
                                         bn_partial, tail_y, tail_bits);
@@ -820,8 +831,8 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
     __syncthreads();
     if (c_tile >= ntiles) break;
     if (s_tile < ntiles) stage(0);
-    compute(smem + (BM + TN_) * BK);
-    finish_ktile(smem + (BM + TN_) * BK);
+    compute(smem + STAGE);
+    finish_ktile(smem + STAGE);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
