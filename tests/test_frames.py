@@ -339,3 +339,78 @@ def test_gpu_jitter_full_size_random_chains(cuda):
     drawn = FR.draw_jitter(4, 0.2, 0.2, 0.2, 0.1, generator=torch.Generator().manual_seed(9))
     b2 = tf(torch.from_numpy(frames[:4]).to(cuda), jitter_params=drawn)
     assert torch.equal(a, b2) and not torch.equal(a, tf(torch.from_numpy(frames[:4]).to(cuda)))
+
+
+@pytest.mark.gpu
+def test_gpu_epoch_from_jpeg_folders(cuda, tmp_path):
+    """The whole caller chain of the reference's training loop on the device-side pipeline: JPEG folders ->
+    RawFrameDataset -> DataLoader(raw_collate) -> DevicePrefetcher (resize, flip off) -> train_epoch /
+    validate_epoch of a small CRNN, against the CPU oracle fed with the host-side transform of the same files
+    (Pillow resize + ToTensor + Normalize, what Dataset_CRNN yields: data_loaders.py:88-108)."""
+    Image = pytest.importorskip("PIL.Image")
+    import types
+
+    import torch.nn as nn
+    from torch.utils import data
+
+    from oracle import torch_oracle as O
+    from video_classification_amd import frames as FR
+    from video_classification_amd import modules as M
+    from video_classification_amd import trainer as TR
+
+    rng = np.random.default_rng(4)
+    folders, labels = [], []
+    yy, xx = np.mgrid[0:72, 0:96]
+    for v in range(4):
+        name = f"v_Class{v}_g01_c01"
+        os.makedirs(tmp_path / name)
+        for i in range(1, 5):
+            img = np.stack([((np.sin(xx / (5.0 + c + v) + i) + np.cos(yy / (7.0 + v))) * 60 + 128) for c in range(3)],
+                           -1).clip(0, 255).astype(np.uint8)
+            Image.fromarray(img).save(str(tmp_path / name / f"frame{i:06d}.jpg"), quality=92)
+        folders.append(name)
+        labels.append(v % 3)
+    frames_sel, S = [1, 2, 3, 4], 64
+
+    ds = FR.RawFrameDataset(str(tmp_path), folders, labels, frames_sel)
+    loader = data.DataLoader(ds, batch_size=2, shuffle=False, collate_fn=FR.raw_collate, num_workers=0)
+    tf = FR.FrameTransform(S, device=cuda)
+    dev_loader = FR.DevicePrefetcher(loader, tf, flip_p=0.0)
+
+    def host_clip(folder):  # the reference's Dataset_CRNN.read_images with the train.py transform, flip off
+        out = []
+        for i in frames_sel:
+            im = Image.open(str(tmp_path / folder / f"frame{i:06d}.jpg")).resize((S, S), Image.BILINEAR)
+            t = torch.from_numpy(np.asarray(im).copy()).permute(2, 0, 1).contiguous().float().div(255)
+            m = torch.tensor(FR.IMAGENET_MEAN)[:, None, None]
+            s = torch.tensor(FR.IMAGENET_STD)[:, None, None]
+            out.append(t.sub_(m).div_(s))
+        return torch.stack(out)
+
+    host_batches = [(torch.stack([host_clip(f) for f in folders[b:b + 2]]),
+                     torch.tensor([[labels[b]], [labels[b + 1]]])) for b in (0, 2)]
+    got = list(dev_loader)
+    assert len(got) == 2 == len(dev_loader)
+    for (hx, hy), (dx, dy) in zip(host_batches, got):
+        assert torch.equal(dx.cpu(), hx) and torch.equal(dy.cpu(), hy)  # the clips are bit-identical
+
+    cfg = types.SimpleNamespace(img_x=S, img_y=S, CNN_fc_hidden1=64, CNN_fc_hidden2=48, CNN_embed_dim=32,
+                                dropout_p=0.0, use_pretrained=False, RNN_hidden_layers=2, RNN_hidden_nodes=32,
+                                RNN_FC_dim=16, num_classes=3)
+    torch.manual_seed(0)
+    ref = O.CRNNModel(cfg)
+    mine = M.CRNNModel(cfg)
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    mine.to(cuda).set_compute_dtype(torch.float32)
+    opt_r = torch.optim.Adam(ref.parameters(), lr=1e-3, weight_decay=1e-4)
+    opt_m = TR.get_optimizer(mine, "adam", lr=1e-3, weight_decay=1e-4)
+    crit = nn.CrossEntropyLoss()
+    losses = [O.train_step(ref, x, y, crit, opt_r)[0] for x, y in host_batches]
+    loss_m, acc_m = TR.train_epoch(mine, dev_loader, TR.FusedCrossEntropyLoss(), opt_m, cuda, 1)
+    assert loss_m == pytest.approx(sum(losses) / len(losses), rel=2e-4)
+    assert 0.0 <= acc_m <= 100.0
+    vloss, vacc = TR.validate_epoch(mine, dev_loader, TR.FusedCrossEntropyLoss(), cuda, 1)
+    ref.eval()
+    with torch.no_grad():
+        want = sum(float(crit(ref(x), y.squeeze(1))) for x, y in host_batches) / 2
+    assert vloss == pytest.approx(want, rel=2e-3)
