@@ -1,4 +1,4 @@
-"""Data-parallel plumbing on CPU with the gloo backend, world size 2 (the N>1 path of bench.py uses the same
+"""Data-parallel plumbing on CPU with the gloo backend, world sizes 2 and 4 (the N>1 path of bench.py uses the same
 classes over RCCL): flat parameter/gradient buffers, bucket partition, gradient-ready notifications, the
 overlapped all-reduce and its finish(), initial broadcast.
 
@@ -56,8 +56,8 @@ def _worker(rank, world, port, bucket_bytes, q):
         assert torch.equal(a, b)  # broadcast from rank 0
 
     g = torch.Generator().manual_seed(42)
-    x = torch.randn(6, 5, 16, generator=g)
-    y = torch.randint(0, 11, (6,), generator=g)
+    x = torch.randn(3 * world, 5, 16, generator=g)
+    y = torch.randint(0, 11, (3 * world,), generator=g)
     xs, ys = x[rank * 3:(rank + 1) * 3], y[rank * 3:(rank + 1) * 3]
     flat.zero_grad()
     bucketer.reset()
@@ -79,9 +79,8 @@ def _worker(rank, world, port, bucket_bytes, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("bucket_bytes", [1 << 30, 4096])
-def test_bucketed_allreduce_matches_full_batch(bucket_bytes):
-    world = 2
+@pytest.mark.parametrize("world,bucket_bytes", [(2, 1 << 30), (2, 4096), (4, 4096)])
+def test_bucketed_allreduce_matches_full_batch(world, bucket_bytes):
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
