@@ -157,6 +157,12 @@ int vc_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* 
                      float* rstd, int M, int C, float eps, vc_stream_t stream);
 int vc_layernorm_bwd(int dtype, const void* x, const void* dout, const float* gamma, const float* mean,
                      const float* rstd, void* dx, float* dgamma, float* dbeta, int M, int C, vc_stream_t stream);
+/* the same with dx = gradient through the normalisation + add (nullable; same shape and type as x): a Swin block's
+ * input feeds norm1 / norm2 and the residual stream, and autograd would otherwise add the two gradients in a pass
+ * of its own */
+int vc_layernorm_bwd_add(int dtype, const void* x, const void* dout, const float* gamma, const float* mean,
+                         const float* rstd, const void* add, void* dx, float* dgamma, float* dbeta, int M, int C,
+                         vc_stream_t stream);
 
 /* ---- layout, pooling, elementwise ------------------------------------------------------------------ */
 /* x_3d[:, t] slicing + NCHW->channels-last (model_components.py:127, 176, 285, 460; Conv3D input

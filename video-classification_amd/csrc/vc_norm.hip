@@ -656,7 +656,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
                                                       const float* __restrict__ gamma, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, T* __restrict__ dx,
                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int M,
-                                                      int C, int rows_per_block) {
+                                                      int C, int rows_per_block, const T* __restrict__ add) {
   extern __shared__ float lds[];  // [2][C]
   constexpr int RPB = 256 / LPR;
   const int C8 = C >> 3;
@@ -710,6 +710,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
           F8 o;
 #pragma unroll
           for (int i = 0; i < 8; ++i) o.v[i] = rs * (dv[k].v[i] * ga[k].v[i] - a - xv[k].v[i] * b);
+          if (add) {  // gradient that reaches x past the normalisation (the residual stream)
+            const F8 r = load8(add + ro + cc * 8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o.v[i] += r.v[i];
+          }
           store8(dx + ro + cc * 8, o);
         }
       }
@@ -1017,9 +1022,21 @@ int vc_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* 
   return VC_OK;
 }
 
+int vc_layernorm_bwd_add(int dtype, const void* x, const void* dout, const float* gamma, const float* mean,
+                         const float* rstd, const void* add, void* dx, float* dgamma, float* dbeta, int M, int C,
+                         hipStream_t stream);
+
 // dgamma/dbeta are accumulated into (caller zeroes or keeps running gradient)
 int vc_layernorm_bwd(int dtype, const void* x, const void* dout, const float* gamma, const float* mean,
                      const float* rstd, void* dx, float* dgamma, float* dbeta, int M, int C, hipStream_t stream) {
+  return vc_layernorm_bwd_add(dtype, x, dout, gamma, mean, rstd, nullptr, dx, dgamma, dbeta, M, C, stream);
+}
+
+// vc_layernorm_bwd with dx = (gradient through the normalisation) + add (nullable, same shape and type as x; may
+// alias dx): the gradient of a tensor that feeds both a LayerNorm and the residual stream, in one pass
+int vc_layernorm_bwd_add(int dtype, const void* x, const void* dout, const float* gamma, const float* mean,
+                         const float* rstd, const void* add, void* dx, float* dgamma, float* dbeta, int M, int C,
+                         hipStream_t stream) {
   VC_CHECK_ARG(x && dout && gamma && mean && rstd && dx && dgamma && dbeta, "vc_layernorm_bwd: null pointer");
   VC_CHECK_SHAPE(C % 8 == 0 && C <= 2048 && M > 0, "vc_layernorm_bwd: need C %% 8 == 0 and C <= 2048 (C=%d)", C);
   // lanes per row / chunks per lane: (16,1) C<=128, (32,1) C<=256, (64,1) C<=512, (64,2) C<=1024, (64,4) C<=2048
@@ -1030,7 +1047,7 @@ int vc_layernorm_bwd(int dtype, const void* x, const void* dout, const float* ga
   const size_t lds = 2 * (size_t)C * sizeof(float);
 #define VC_LN_BWD(T, LPR, NCH)                                                                                  \
   hipLaunchKernelGGL((ln_bwd_kernel<T, LPR, NCH>), grid, dim3(256), lds, stream, (const T*)x, (const T*)dout,   \
-                     gamma, mean, rstd, (T*)dx, dgamma, dbeta, M, C, rows_per_block)
+                     gamma, mean, rstd, (T*)dx, dgamma, dbeta, M, C, rows_per_block, (const T*)add)
 #define VC_LN_BWD_ALL(T)                                       \
   if (lpr == 16) VC_LN_BWD(T, 16, 1);                          \
   else if (lpr == 32) VC_LN_BWD(T, 32, 1);                     \

@@ -1349,6 +1349,50 @@ def layer_norm(x, ln):
     return _LayerNorm.apply(x, ln.weight, ln.bias, ln.eps)
 
 
+class _LayerNormFork(torch.autograd.Function):
+    """(x, LayerNorm(x)): x goes on into the residual stream, its normalised copy into the branch.  The gradient
+    of x is the sum of the two; the LayerNorm backward kernel adds the residual-stream gradient as it writes, so
+    autograd never runs an addition pass of its own."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        _require_cuda(x, "layer_norm")
+        ctx.set_materialize_grads(False)
+        x = x.contiguous()
+        C = x.shape[-1]
+        M = x.numel() // C
+        out = torch.empty_like(x)
+        stat = torch.empty(2, M, device=x.device, dtype=torch.float32)
+        L.call("vc_layernorm_fwd", L.dtype_code(x.dtype), L.ptr(x), L.ptr(weight.detach()), L.ptr(bias.detach()),
+               L.ptr(out), L.ptr(stat[0]), L.ptr(stat[1]), M, C, float(eps), L.stream())
+        ctx.weight, ctx.bias = weight, bias
+        ctx.save_for_backward(x, stat)
+        return x.view_as(x), out
+
+    @staticmethod
+    def backward(ctx, dres, dout):
+        x, stat = ctx.saved_tensors
+        if dout is None:
+            return dres, None, None, None
+        C = x.shape[-1]
+        M = x.numel() // C
+        dout = cast(dout.contiguous(), x.dtype)
+        if dres is not None:
+            dres = cast(dres.contiguous(), x.dtype)
+        dx = torch.empty_like(x)
+        w, b = ctx.weight, ctx.bias
+        L.call("vc_layernorm_bwd_add", L.dtype_code(x.dtype), L.ptr(x), L.ptr(dout), L.ptr(w.detach()),
+               L.ptr(stat[0]), L.ptr(stat[1]), L.ptr(dres), L.ptr(dx), L.ptr(_grad_buf(w)), L.ptr(_grad_buf(b)), M, C,
+               L.stream())
+        _ready(w, b)
+        return dx, None, None, None
+
+
+def layer_norm_fork(x, ln):
+    """Returns (x, LayerNorm(x)) for a tensor that continues in the residual stream; see _LayerNormFork."""
+    return _LayerNormFork.apply(x, ln.weight, ln.bias, ln.eps)
+
+
 class _Gelu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

@@ -47,8 +47,7 @@ class SwinBlock(nn.Module):
     def run(self, x, drop_path, training):
         """x: [F, H, W, C] tokens in the compute dtype."""
         F_, H, W, C = x.shape
-        t = x.view(F_ * H * W, C)
-        y = ops.layer_norm(t, self.norm1)
+        t, y = ops.layer_norm_fork(x.view(F_ * H * W, C), self.norm1)
         qkv = ops.linear(y, self.attn.qkv.weight, self.attn.qkv.bias)
         a = ops.window_attention(qkv, self.attn.relative_position_bias_table, F_, H, W, self.attn.heads, self.ws,
                                  self.shift)
@@ -58,7 +57,7 @@ class SwinBlock(nn.Module):
             t = ops.add(t, ops.drop_path(a, drop_path, training, F_))
         else:         # x + proj(attn) in the projection GEMM's epilogue
             t = ops.linear(a, self.attn.proj.weight, self.attn.proj.bias, residual=t)
-        y = ops.layer_norm(t, self.norm2)
+        t, y = ops.layer_norm_fork(t, self.norm2)
         h = ops.linear(y, self.mlp.fc1.weight, self.mlp.fc1.bias)
         # fc2 is applied to gelu(h); the gradient through the GELU is taken in fc2's data-gradient GEMM
         if dropping:
