@@ -272,6 +272,23 @@ def test_layernorm(cuda, dt, M, C):
     assert G.max_rel(xm.grad.float().cpu(), xr.grad) < 2 * t
     assert G.max_rel(ln_m.weight.grad.cpu(), ln_r.weight.grad) < 2 * t
     assert G.max_rel(ln_m.bias.grad.cpu(), ln_r.bias.grad) < 2 * t
+    # the fork form: x continues in the residual stream, its gradient is added inside the backward kernel
+    ln_r.zero_grad()
+    ln_m.zero_grad()
+    dres = rnd(dt, M, C, seed=24)
+    xr = x.clone().requires_grad_(True)
+    (ln_r(xr) * dy + xr * dres).sum().backward()
+    xm = x.to(cuda, dt).requires_grad_(True)
+    xs, ym = ops.layer_norm_fork(xm, ln_m)
+    assert torch.equal(xs, xm)
+    torch.autograd.backward([ym, xs], [dy.to(cuda, dt), dres.to(cuda, dt)])
+    assert G.max_rel(xm.grad.float().cpu(), xr.grad) < 2 * t
+    assert G.max_rel(ln_m.weight.grad.cpu(), ln_r.weight.grad) < 2 * t
+    # only one of the two outputs used downstream
+    xm2 = x.to(cuda, dt).requires_grad_(True)
+    xs2, _ = ops.layer_norm_fork(xm2, ln_m)
+    xs2.backward(dres.to(cuda, dt))
+    assert G.max_rel(xm2.grad.float().cpu(), dres) < 1e-6
 
 
 @pytest.mark.parametrize("T,B,In,H,layers,bidir", [(16, 32, 512, 512, 2, False), (16, 8, 192, 512, 2, True),
