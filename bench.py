@@ -20,7 +20,7 @@ The JSON line also carries
                  timed region / their summed durations from HIP events on the launch stream) against the dense
                  bf16 MFMA peak of 2.5 PFLOP/s.
   cpu_baseline : the CPU oracle (oracle/torch_oracle.py, same architecture, fp32) timed on this host for a
-                 bounded sample (2 clips per step), rank 0 / N=1 only.
+                 bounded sample (10 steps of 2 clips), rank 0 / N=1 only.
 """
 import argparse
 import json
@@ -127,7 +127,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     ap.add_argument("--cpu-batch", type=int, default=2)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--bucket-mb", type=int, default=32)
     ap.add_argument("--infer", action="store_true",
                     help="time the eval-mode forward (predict.py / save_predictions callers) instead of a training step")
