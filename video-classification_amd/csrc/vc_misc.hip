@@ -57,7 +57,7 @@ __global__ void clip_to_cl_kernel(const float* __restrict__ x, T* __restrict__ o
 template <typename T>
 __global__ void clip_unfold_w_kernel(const float* __restrict__ x, T* __restrict__ out, int B, int Tn, int C, int H,
                                      int W, int Wo, int kw, int sw, int pw, int Jp, int time_major, int chan_outer) {
-  extern __shared__ float srow[];  // [C][W]
+  extern __shared__ __attribute__((aligned(16))) float srow[];  // [C][W]
   const int S = H * W;
   const int fh = blockIdx.x;       // frame * H + h
   const int h = fh % H, f = fh / H;
@@ -69,29 +69,42 @@ __global__ void clip_unfold_w_kernel(const float* __restrict__ x, T* __restrict_
     b = f / Tn;
     t = f - b * Tn;
   }
-  for (int i = threadIdx.x; i < C * W; i += blockDim.x) {
-    const int c = i / W, w = i - c * W;
-    const size_t src = chan_outer ? (((size_t)b * C + c) * Tn + t) * S + (size_t)h * W + w
-                                  : (((size_t)b * Tn + t) * C + c) * S + (size_t)h * W + w;
-    srow[i] = x[src];
+  for (int c = 0; c < C; ++c) {  // one source row per channel, 16-byte loads where the row allows
+    const float* row = x + (chan_outer ? (((size_t)b * C + c) * Tn + t) * S : (((size_t)b * Tn + t) * C + c) * S) +
+                       (size_t)h * W;
+    if ((W & 3) == 0 && (reinterpret_cast<uintptr_t>(row) & 15) == 0) {
+      for (int i = threadIdx.x; i < (W >> 2); i += blockDim.x)
+        reinterpret_cast<f32x4*>(srow + c * W)[i] = reinterpret_cast<const f32x4*>(row)[i];
+    } else {
+      for (int i = threadIdx.x; i < W; i += blockDim.x) srow[c * W + i] = row[i];
+    }
   }
   __syncthreads();
   const int J8 = Jp >> 3, kwc = kw * C;
-  for (int i = threadIdx.x; i < Wo * J8; i += blockDim.x) {  // one 8-channel chunk of one output pixel
-    const int wo = i / J8, ch = i - wo * J8;
+  // one 8-channel chunk of one output pixel per step; the (tap, channel) of the chunk's first element is found by
+  // counting, so that the loop has no integer divisions
+  for (int wo = threadIdx.x / J8, ch = threadIdx.x - wo * J8; wo < Wo;) {
+    int q = ch * 8, j = q / C, c = q - j * C;
+    const int w0 = wo * sw - pw;
     F8 v;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int q = ch * 8 + e;
+    for (int e = 0; e < 8; ++e, ++q) {
       float val = 0.f;
-      if (q < kwc) {
-        const int j = q / C, c = q - j * C;
-        const int w = wo * sw - pw + j;
-        if ((unsigned)w < (unsigned)W) val = srow[c * W + w];
-      }
+      if (q < kwc && (unsigned)(w0 + j) < (unsigned)W) val = srow[c * W + w0 + j];
       v.v[e] = val;
+      if (++c == C) {
+        c = 0;
+        ++j;
+      }
     }
     store8(out + ((size_t)fh * Wo + wo) * Jp + ch * 8, v);
+    // advance by blockDim.x chunks
+    ch += blockDim.x % J8;
+    wo += blockDim.x / J8;
+    if (ch >= J8) {
+      ch -= J8;
+      ++wo;
+    }
   }
 }
 
