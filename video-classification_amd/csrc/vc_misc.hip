@@ -163,19 +163,17 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, u
 template <typename T>
 __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx, T* __restrict__ dx, int N,
                                    int H, int W, int C8, int Ho, int Wo, int k, int s, int p) {
-  const int64_t total = (int64_t)N * H * W * C8;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int cc = (int)(i % C8);
-    int64_t t = i / C8;
-    const int iw = (int)(t % W);
-    t /= W;
-    const int ih = (int)(t % H);
-    const int n = (int)(t / H);
+  // one block row per (sample, image row): the only division left is the one that splits a row item into
+  // (column, channel chunk)
+  const int ih = blockIdx.y, n = blockIdx.z;
+  const int oh_lo = max(0, (ih + p - k + s) / s), oh_hi = min(Ho - 1, (ih + p) / s);
+  for (int it = blockIdx.x * blockDim.x + threadIdx.x; it < W * C8; it += gridDim.x * blockDim.x) {
+    const int iw = it / C8, cc = it - iw * C8;
+    const int64_t i = ((int64_t)n * H + ih) * W * C8 + it;
     F8 acc;
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc.v[j] = 0.f;
     // output windows that contain (ih, iw): oh*s - p <= ih <= oh*s - p + k - 1
-    const int oh_lo = max(0, (ih + p - k + s) / s), oh_hi = min(Ho - 1, (ih + p) / s);
     const int ow_lo = max(0, (iw + p - k + s) / s), ow_hi = min(Wo - 1, (iw + p) / s);
     for (int oh = oh_lo; oh <= oh_hi; ++oh) {
       const int r = ih - (oh * s - p);
@@ -554,10 +552,11 @@ int vc_maxpool2d_bwd(int dtype, const void* dy, const uint8_t* idx, void* dx, in
   VC_CHECK_ARG(dy && idx && dx, "vc_maxpool2d_bwd: null pointer");
   VC_CHECK_SHAPE(C % 8 == 0 && k > 0 && s > 0 && p >= 0 && p < k, "vc_maxpool2d_bwd: bad shape");
   const int Ho = (H + 2 * p - k) / s + 1, Wo = (W + 2 * p - k) / s + 1;
-  const int64_t total = (int64_t)N * H * W * (C / 8);
+  VC_CHECK_SHAPE(H <= 65535 && N <= 65535, "vc_maxpool2d_bwd: at most 65535 rows and samples");
+  const dim3 grid(ceil_div(W * (C / 8), NTHR), H, N);
   DISPATCH_T(dtype, "vc_maxpool2d_bwd",
-             hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(ew_grid(total)), dim3(NTHR), 0, stream, (const T*)dy, idx,
-                                (T*)dx, N, H, W, C / 8, Ho, Wo, k, s, p);)
+             hipLaunchKernelGGL((maxpool_bwd_kernel<T>), grid, dim3(NTHR), 0, stream, (const T*)dy, idx, (T*)dx, N, H, W,
+                                C / 8, Ho, Wo, k, s, p);)
   VC_LAUNCH_CHECK("vc_maxpool2d_bwd");
   return VC_OK;
 }
