@@ -66,6 +66,11 @@ int vc_conv_dgrad(const int* desc, int dtype, const void* dy, int lddy, const vo
 int vc_conv_dgrad_bn_tail_supported(const int* desc, int dtype);
 int vc_conv_dgrad_bn_tail(const int* desc, int dtype, const void* dy, const void* w_packed_t, void* dx, int beta,
                           const void* tail_y, const uint8_t* tail_bits, float* bn_partial, vc_stream_t stream);
+/* fc1 of a Swin / ViT MLP (timm Mlp: fc1 -> GELU -> fc2, created at model_components.py:254, 412): y = conv(x) + bias
+ * and y_gelu = gelu(y) written by the same epilogue, so the activation is not a pass of its own.  Same geometries
+ * as vc_conv_fwd_residual (vc_conv_epilogue_side_supported(desc, dtype, 0)). */
+int vc_conv_fwd_gelu_dual(const int* desc, int dtype, const void* x, const void* w_packed, const float* bias, void* y,
+                          void* y_gelu, vc_stream_t stream);
 /* GEMM epilogues that read a side tensor of the output's own layout (bf16, dense rows, more than 64 output columns;
  * vc_conv_epilogue_side_supported(desc, dtype, mode: 0 forward, 1 data gradient) says whether a geometry qualifies):
  * vc_conv_fwd_residual: y = conv(x) + bias + residual, out of place -- the x + attn(x) / x + mlp(x) of the Swin blocks

@@ -258,3 +258,16 @@ def test_epilogue_side_tensor_forms(cuda):
     gp = 0.5 * (1 + torch.erf(p / 2 ** 0.5)) + p * torch.exp(-0.5 * p * p) / (2 * torch.pi) ** 0.5
     ref = d0.float().cpu().double() * gp
     assert _rel(d1.float().cpu(), ref.float()) < 1e-2
+    # forward with two outputs: y identical to the plain forward, and gelu of y as stored (bf16)
+    yb = torch.empty(M, N, device=cuda, dtype=torch.bfloat16)
+    y2 = torch.empty(M, N, device=cuda, dtype=torch.bfloat16)
+    gl = torch.empty(M, N, device=cuda, dtype=torch.bfloat16)
+    L.call("vc_conv_fwd", desc, 1, L.ptr(x), 0, L.ptr(wf), L.ptr(bias), L.ptr(yb), 0, 0, 0, 0, L.stream())
+    L.call("vc_conv_fwd_gelu_dual", desc, 1, L.ptr(x), L.ptr(wf), L.ptr(bias), L.ptr(y2), L.ptr(gl), L.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(y2, yb)
+    h = yb.float().cpu().double()
+    want = (0.5 * h * (1 + torch.erf(h / 2 ** 0.5))).float()
+    # erff on the device against erf in double: a few fp32 ulps before the rounding to bf16
+    assert _rel(gl.float().cpu(), want) < 4e-3
+    assert (gl.float().cpu() - want.bfloat16().float()).abs().max() <= 2 * want.abs().max() * 2 ** -8

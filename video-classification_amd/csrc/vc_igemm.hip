@@ -497,7 +497,10 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_fast_kernel(ConvGeom g, cons
 //   BatchNorm's input).
 // EPI_RESIDUAL: out = result + tail_y (a transformer block's x + f(x), written out of place).
 // EPI_GELU_BWD: out = result * gelu'(tail_y) (the gradient through a GELU whose input tail_y was kept).
-constexpr int EPI_NONE = 0, EPI_BN_TAIL = 1, EPI_RESIDUAL = 2, EPI_GELU_BWD = 3;
+// EPI_GELU_DUAL: out = result, and gelu(result as stored) goes to a second tensor of the same layout whose address
+// arrives in tail_y (the only mode that writes through that pointer).
+constexpr int EPI_NONE = 0, EPI_BN_TAIL = 1, EPI_RESIDUAL = 2, EPI_GELU_BWD = 3, EPI_GELU_DUAL = 4;
+__device__ __forceinline__ float gelu_dev(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
 __device__ __forceinline__ float gelu_grad_dev(float x) {  // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
   const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
@@ -551,7 +554,8 @@ __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[
   bf16x8 oldv[NIT];
   bf16* orow[NIT];
   constexpr bool TAIL = EPI == EPI_BN_TAIL;
-  bf16x8 tyv[EPI != EPI_NONE ? NIT : 1];
+  constexpr bool SIDE_IN = EPI != EPI_NONE && EPI != EPI_GELU_DUAL;  // tail_y is read
+  bf16x8 tyv[SIDE_IN ? NIT : 1];
   unsigned tbits[TAIL ? NIT : 1];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
@@ -560,7 +564,7 @@ __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[
     orow[it] = live ? out + (size_t)(MODE == 2 ? phase_out_pixel(g, m) : m) * g.ldc + co : nullptr;
     oldv[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
     if (beta && live && vec) oldv[it] = *reinterpret_cast<const bf16x8*>(orow[it]);
-    if (EPI != EPI_NONE) {
+    if (SIDE_IN) {
       tyv[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
       if (live) tyv[it] = *reinterpret_cast<const bf16x8*>(tail_y + (size_t)m * g.Co + co);
     }
@@ -594,6 +598,14 @@ __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[
         pq[e] = fmaf(dz, (float)tyv[it][e], pq[e]);
       }
       if (op) *reinterpret_cast<bf16x8*>(op) = v;
+    } else if (EPI == EPI_GELU_DUAL) {  // host guarantees vec and beta == 0
+      if (op) {
+        bf16x8 gv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gv[e] = (bf16)gelu_dev((float)v[e]);
+        *reinterpret_cast<bf16x8*>(op) = v;
+        *reinterpret_cast<bf16x8*>(const_cast<bf16*>(tail_y) + (size_t)m * g.Co + co) = gv;
+      }
     } else if (EPI == EPI_RESIDUAL || EPI == EPI_GELU_BWD) {  // host guarantees vec
       if (op) {
 #pragma unroll
@@ -1662,6 +1674,25 @@ int vc_conv_fwd_residual(const int* desc, int dtype, const void* x, const void* 
                      (const bf16*)x, (const bf16*)w_packed, bias, y, 0, 0, 0, tiles, (float*)nullptr,
                      (const bf16*)residual, (const uint8_t*)nullptr);
   VC_LAUNCH_CHECK("vc_conv_fwd_residual");
+  return VC_OK;
+}
+
+// y = conv(x) + bias and y_gelu = gelu(y) (of the value as stored in y) in one pass: the activation between the two
+// linear layers of an MLP without a pass of its own.  Geometries: vc_conv_epilogue_side_supported(desc, dtype, 0).
+int vc_conv_fwd_gelu_dual(const int* desc, int dtype, const void* x, const void* w_packed, const float* bias, void* y,
+                          void* y_gelu, hipStream_t stream) {
+  ConvGeom g;
+  int rc = fill_geom(g, desc, 0, "vc_conv_fwd_gelu_dual");
+  if (rc) return rc;
+  VC_CHECK_ARG(x && w_packed && y && y_gelu, "vc_conv_fwd_gelu_dual: null pointer");
+  VC_CHECK_SHAPE(dgrad_tail_eligible(g, dtype),
+                 "vc_conv_fwd_gelu_dual: unsupported geometry (ask vc_conv_epilogue_side_supported)");
+  const int tiles = ceil_div(g.M, BM) * ceil_div(g.Co, BN);
+  const int grid = tiles < nt_persist_blocks() ? tiles : nt_persist_blocks();
+  hipLaunchKernelGGL((igemm_nt_persist_kernel<0, 128, EPI_GELU_DUAL>), dim3(grid), dim3(NTHR), 0, stream, g,
+                     (const bf16*)x, (const bf16*)w_packed, bias, y, 0, 0, 0, tiles, (float*)nullptr,
+                     (const bf16*)y_gelu, (const uint8_t*)nullptr);
+  VC_LAUNCH_CHECK("vc_conv_fwd_gelu_dual");
   return VC_OK;
 }
 

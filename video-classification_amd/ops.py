@@ -180,7 +180,7 @@ class _Conv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, kernel, stride, padding, relu, out_f32, ci, join, stats_groups, residual=None,
-                pre_gelu=False):
+                pre_gelu=False, want_gelu=False, gelu_x=None):
         _require_cuda(x, "conv")
         ctx.join = join
         # the slab-sum output never carries a gradient: do not let autograd fill a zero tensor of its size per call
@@ -191,7 +191,9 @@ class _Conv(torch.autograd.Function):
         ctx.pre = None
         if pre_gelu:
             ctx.pre = x
-            x = elementwise(3, x)
+            # gelu(x) may come with x from the layer that produced it (want_gelu there), else it is a pass here
+            x = gelu_x.contiguous().view(x.shape) if gelu_x is not None and gelu_x.numel() == x.numel() \
+                else elementwise(3, x)
         dtype = x.dtype
         N, D, H, W, cip = x.shape
         co = weight.shape[0]
@@ -229,6 +231,7 @@ class _Conv(torch.autograd.Function):
         flops = 2.0 * N * Do * Ho * Wo * co * ci * taps  # algorithmic: true channel counts, no padding
         M = N * Do * Ho * Wo
         partial = None
+        g_out = None
         # algorithmic HBM bytes of one launch: the input, the packed weight and the output, each moved once
         nbytes = float(x.numel() * x.element_size() + wf.numel() * wf.element_size() + y.numel() * y.element_size())
         if (stats_groups and FUSE_BN_STATS and not f32 and M % stats_groups == 0 and (M // stats_groups) % 64 == 0 and
@@ -238,6 +241,12 @@ class _Conv(torch.autograd.Function):
             _timed("conv_fwd", flops, lambda: L.call(
                 "vc_conv_fwd_stats", L.int_array(desc), L.dtype_code(dtype), L.ptr(x), 0, L.ptr(wf), L.ptr(b),
                 L.ptr(y), 0, int(relu), L.ptr(partial), L.stream()), nbytes)
+        elif (want_gelu and residual is None and FUSE_EPILOGUE_SIDE and not f32 and not relu and
+              L.query("vc_conv_epilogue_side_supported", L.int_array(desc), L.dtype_code(dtype), 0) == 1):
+            g_out = torch.empty_like(y)  # gelu(y), written by the same epilogue
+            _timed("conv_fwd", flops, lambda: L.call(
+                "vc_conv_fwd_gelu_dual", L.int_array(desc), L.dtype_code(dtype), L.ptr(x), L.ptr(wf), L.ptr(b),
+                L.ptr(y), L.ptr(g_out), L.stream()), nbytes + float(y.numel() * y.element_size()))
         elif (residual is not None and FUSE_EPILOGUE_SIDE and not f32 and not relu and
               tuple(residual.shape) == tuple(y.shape) and residual.dtype == y.dtype and
               L.query("vc_conv_epilogue_side_supported", L.int_array(desc), L.dtype_code(dtype), 0) == 1):
@@ -259,11 +268,13 @@ class _Conv(torch.autograd.Function):
         ctx.save_for_backward(x, wt, y if relu else None)
         if partial is None:
             partial = y.new_empty(0, dtype=torch.float32)
-        ctx.mark_non_differentiable(partial)
-        return y, partial
+        if g_out is None:
+            g_out = y.new_empty(0)
+        ctx.mark_non_differentiable(partial, g_out)
+        return y, partial, g_out
 
     @staticmethod
-    def backward(ctx, dy, _dpartial=None):
+    def backward(ctx, dy, _dpartial=None, _dgelu=None):
         x, wt, y = ctx.saved_tensors
         co, ci, cip, cop = ctx.dims
         if dy is None:  # nothing flows back into this layer
@@ -349,7 +360,7 @@ class _Conv(torch.autograd.Function):
             main.wait_stream(side)
         _ready(weight, bias)
         dres = dy if (len(ctx.needs_input_grad) > 11 and ctx.needs_input_grad[11]) else None
-        grads = (dx, None, None, None, None, None, None, None, None, None, None, dres, None)
+        grads = (dx, None, None, None, None, None, None, None, None, None, None, dres, None, None, None)
         return grads[:len(ctx.needs_input_grad)]
 
 
@@ -532,25 +543,32 @@ def conv_bn(x, weight, bn, groups, bias=None, kernel=1, stride=1, padding=0, rel
     """BatchNorm(conv(x)) (+ residual, ReLU).  In training the convolution's epilogue also writes the slab sums
     the BatchNorm statistics are taken from, where the geometry allows it (otherwise a separate pass reads y)."""
     training = bn.training or bn.running_mean is None
-    y, partial = _Conv.apply(x, weight, bias, kernel, stride, padding, False, False, None, join,
-                             groups if training else 0)
+    y, partial, _ = _Conv.apply(x, weight, bias, kernel, stride, padding, False, False, None, join,
+                                groups if training else 0)
     if pool is not None:  # (k, s, p) of the max-pool that follows BatchNorm + ReLU
         return batch_norm_relu_pool(y, bn, groups, *pool, partial=partial if partial.numel() else None)
     return batch_norm(y, bn, groups, relu=relu, residual=residual, res_join=res_join,
                       partial=partial if partial.numel() else None, grad_inplace=grad_inplace)
 
 
-def linear(x, weight, bias=None, relu=False, out_f32=False, residual=None, pre_gelu=False):
+def linear(x, weight, bias=None, relu=False, out_f32=False, residual=None, pre_gelu=False, want_gelu=False,
+           gelu_x=None):
     """x: [M, C] -> [M, pad8(Co)].  residual: [M, pad8(Co)] added to the result (in the GEMM's epilogue where the
     geometry allows).  pre_gelu: the layer is applied to gelu(x); the gradient through the GELU is then taken in the
-    data-gradient GEMM's epilogue."""
+    data-gradient GEMM's epilogue; gelu_x, if given, is gelu(x) as the producing layer wrote it.  want_gelu: returns
+    (y, gelu(y)), the second from the same epilogue (None where the geometry does not allow it: the consumer then
+    computes it)."""
     M, C = x.shape
-    if residual is None and not pre_gelu:
+    if residual is None and not pre_gelu and not want_gelu:
         y = conv(x.view(M, 1, 1, 1, C), weight, bias, 1, 1, 0, relu, out_f32)
-    else:
-        res = residual.view(M, 1, 1, 1, residual.shape[-1]) if residual is not None else None
-        y = _Conv.apply(x.view(M, 1, 1, 1, C), weight, bias, 1, 1, 0, relu, out_f32, None, None, 0, res, pre_gelu)[0]
-    return y.view(M, y.shape[-1])
+        return y.view(M, y.shape[-1])
+    res = residual.view(M, 1, 1, 1, residual.shape[-1]) if residual is not None else None
+    y, _, g = _Conv.apply(x.view(M, 1, 1, 1, C), weight, bias, 1, 1, 0, relu, out_f32, None, None, 0, res, pre_gelu,
+                          want_gelu, gelu_x)
+    y = y.view(M, y.shape[-1])
+    if want_gelu:
+        return y, (g.view(M, y.shape[-1]) if g.numel() else None)
+    return y
 
 
 # ----------------------------------------------------------------------------------------------

@@ -58,13 +58,13 @@ class SwinBlock(nn.Module):
         else:         # x + proj(attn) in the projection GEMM's epilogue
             t = ops.linear(a, self.attn.proj.weight, self.attn.proj.bias, residual=t)
         t, y = ops.layer_norm_fork(t, self.norm2)
-        h = ops.linear(y, self.mlp.fc1.weight, self.mlp.fc1.bias)
+        h, gh = ops.linear(y, self.mlp.fc1.weight, self.mlp.fc1.bias, want_gelu=True)  # fc1 and gelu(fc1)
         # fc2 is applied to gelu(h); the gradient through the GELU is taken in fc2's data-gradient GEMM
         if dropping:
-            y = ops.linear(h, self.mlp.fc2.weight, self.mlp.fc2.bias, pre_gelu=True)
+            y = ops.linear(h, self.mlp.fc2.weight, self.mlp.fc2.bias, pre_gelu=True, gelu_x=gh)
             t = ops.add(t, ops.drop_path(y, drop_path, training, F_))
         else:
-            t = ops.linear(h, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=t, pre_gelu=True)
+            t = ops.linear(h, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=t, pre_gelu=True, gelu_x=gh)
         return t.view(F_, H, W, C)
 
 
