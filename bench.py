@@ -106,6 +106,37 @@ def cpu_baseline(args):
             "sample": f"{n} training steps of {b} clips {tuple(shape[1:])} after 1 warm-up, fp32, same architecture"}
 
 
+def spawn_ranks(n):
+    """One child process per rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torch.distributed.run sets them),
+    same command line; rank 0 prints the JSON line.  Returns the worst exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "4")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        for p in procs:
+            code = p.wait()
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                for q in procs:  # a rank died: the others would wait in a collective forever
+                    if q.poll() is None:
+                        q.terminate()
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+    return rc
+
+
 def trace(msg):
     """Progress marks on stderr (VC_BENCH_TRACE=1): where a multi-rank run is, should it stall."""
     if os.environ.get("VC_BENCH_TRACE", "0") == "1":
@@ -134,6 +165,11 @@ def main():
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 8 if args.model in ("swinrnn", "clusterswin") else 32
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly as `python bench.py --gpus N`: this process becomes the launcher.  It has not touched the
+        # GPU and never will; it starts one fresh rank process per GPU and ends with their worst exit code.
+        raise SystemExit(spawn_ranks(args.gpus))
 
     from video_classification_amd import modules as M
     from video_classification_amd import swin as S

@@ -3,6 +3,7 @@ classes, full-width models, against the CPU oracle with identical weights and in
 every parameter gradient.  The oracle's forward + backward takes about 10 s per model on 8-16 host cores.
 
   ResNetCRNN   ResCNNEncoder(ResNet-50 trunk, 1024/768/512) + DecoderRNN(2 x 512, FC 256), configs[1], 6 clips
+  Swin-RNN     SwinTransformerEncoder(Swin-T, 1024/768/512) + DecoderRNN(3 x 512, FC 256), configs[3], 6 clips
   clusterSwin  ClusterSwinEncoder(Swin-T, E = 96, k = 8) + TCG_LSTM(H = 512, L = 2), configs[4], 4 clips
   Conv3D       Conv3DModel at its native 1 x 16 x 112 x 112, configs[2], 4 clips
 
@@ -156,6 +157,64 @@ def test_cluster_swin_tcg_ucf_shape(cuda, dt):
     ops.check_lstm_error()
     # measured: fp32 worst 8e-6 (patch embedding); bf16 worst 1.5e-2 (a stage-4 bias table), decoder 7e-3
     _compare(mine, out, loss.item(), ref_out, ref_loss, ref_grads, dt, 1e-4 if dt == torch.float32 else 5e-2)
+
+
+@functools.lru_cache(maxsize=None)
+def _swin_rnn_ref():
+    from oracle import torch_oracle as O
+    torch.manual_seed(14)
+    # what the reference's factory builds for --model swintransformer-RNN (train.py:256-278 with the Config defaults
+    # of models/swintransformer_RNN/UCF101_SwinCRNN_fixed.py:72-80 and create_model, :404-423)
+    ref = O.SwinTransformerRNNModel(O.SwinTransformerEncoder(1024, 768, 0.0, 512), O.DecoderRNN(512, 3, 512, 256, 0.0, 101))
+    g = torch.Generator().manual_seed(777)
+    B = 6
+    x = torch.randn(B, 16, 3, 224, 224, generator=g)
+    y = torch.randint(0, 101, (B, 1), generator=g)
+    ref.train()
+    out = ref(x)
+    loss = nn.CrossEntropyLoss()(out, y.squeeze(1))
+    loss.backward()
+    bufs = {k: v.clone() for k, v in ref.named_buffers()}
+    return ref.state_dict(), x, y, out.detach(), loss.item(), {k: p.grad for k, p in ref.named_parameters()}, bufs
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("dt", DTYPES, ids=IDS)
+def test_swin_rnn_ucf_shape(cuda, dt):
+    """configs[3], the assembled swintransformer-RNN model: Swin-T backbone -> BatchNorm1d head with per-time-step
+    statistics over the 6 clips -> 3 x 512 LSTM -> FC, 16 x 3 x 224 x 224 clips.  Logits, loss, predictions, every
+    gradient and the head's running statistics after the step against the CPU oracle."""
+    from video_classification_amd import modules as M
+    from video_classification_amd import ops
+    from video_classification_amd import swin as S
+    mine = M.SwinTransformerRNNModel(S.SwinTransformerEncoder(1024, 768, 0.0, 512), M.DecoderRNN(512, 3, 512, 256, 0.0, 101))
+    sd, x, y, ref_out, ref_loss, ref_grads, ref_bufs = _swin_rnn_ref()
+    # the oracle's state_dict is taken AFTER its training-mode forward: running statistics start from the defaults
+    sd0 = {k: v for k, v in sd.items() if not ("running_" in k or "num_batches" in k)}
+    missing, unexpected = mine.load_state_dict(sd0, strict=False)
+    assert not unexpected and all(("running_" in k or "num_batches" in k) for k in missing)
+    mine.to(cuda).set_compute_dtype(dt)
+    mine.train()
+    out = mine(x.to(cuda))
+    loss = ops.cross_entropy(out, y.to(cuda))
+    loss.backward()
+    torch.cuda.synchronize()
+    ops.check_lstm_error()
+    f32 = dt == torch.float32
+    # measured: fp32 backbone 1.2e-4, head and decoder < 1e-5; bf16 backbone 0.50, head 0.05-0.20 (BatchNorm1d over 6
+    # samples per time step amplifies the rounding of everything in front of it, as in the ResNet test), decoder 1.2e-2
+    _compare(mine, out, loss.item(), ref_out, ref_loss, ref_grads, dt, 2e-3 if f32 else 0.7,
+             group_tol={"decoder.": 1e-4, "encoder.fc": 1e-4, "encoder.bn": 1e-4} if f32 else
+             {"decoder.fc": 2e-2, "decoder.": 5e-2, "encoder.fc3": 5e-2},
+             # constant shifts in front of a BatchNorm have a zero true gradient: the head's biases, and the
+             # backbone's last LayerNorm bias (it passes the token mean and fc1 unchanged for every sample)
+             cancelled=["encoder.fc1.bias", "encoder.fc2.bias", "encoder.swin.norm.bias"])
+    mb = dict(mine.named_buffers())
+    for k, v in ref_bufs.items():
+        if k.endswith("num_batches_tracked"):
+            assert int(mb[k]) == int(v) == 16, k   # one update per time step
+        elif "running_" in k:
+            assert G.max_rel(mb[k].cpu(), v) < (1e-4 if f32 else 2e-2), k
 
 
 @functools.lru_cache(maxsize=None)

@@ -232,6 +232,49 @@ def test_fused_optimizers_match_torch(cuda, name, kw):
         assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}
 
 
+@pytest.mark.parametrize("name", ["adam", "sgd"])
+def test_fused_optimizer_resumes_torch_state(cuda, name):
+    """A torch.optim state_dict taken after two steps (momentum / moments in place) is loaded into a fresh fused
+    optimizer; the third step must equal torch's third step.  One parameter never receives a gradient: torch keeps no
+    state for it, and a caller's model.zero_grad() (set_to_none) detaches every .grad from the flat buffer."""
+    from video_classification_amd import trainer as TR
+    torch.manual_seed(0)
+    ref = nn.Sequential(nn.Linear(13, 7), nn.Linear(7, 5), nn.Linear(5, 3))
+    mine = nn.Sequential(nn.Linear(13, 7), nn.Linear(7, 5), nn.Linear(5, 3))
+    kw = dict(lr=1e-2, weight_decay=1e-4)
+    opt_r = torch.optim.SGD(ref.parameters(), momentum=0.9, **kw) if name == "sgd" else torch.optim.Adam(ref.parameters(), **kw)
+    unused = {id(p) for p in ref[2].parameters()}
+
+    def grads(model, step, to=None):
+        for p, q in zip(ref.parameters(), model.parameters()):
+            if id(p) in unused:
+                continue
+            g = torch.randn(p.shape, generator=torch.Generator().manual_seed(200 + step))
+            q.grad = g.clone().to(to) if to is not None else g.clone()
+
+    for step in range(2):
+        opt_r.zero_grad()
+        grads(ref, step)
+        opt_r.step()
+    mine.load_state_dict(ref.state_dict())
+    mine.to(cuda)
+    opt_m = TR.FusedOptimizer(mine, name, **kw)
+    opt_m.load_state_dict(opt_r.state_dict())
+    opt_r.zero_grad()
+    grads(ref, 2)
+    opt_r.step()
+    mine.zero_grad()            # set_to_none: the parameters lose their views of the flat gradient buffer
+    opt_m.flat.zero_grad()
+    grads(mine, 2, to=cuda)     # ... and receive freshly allocated gradients
+    opt_m.step()
+    for (k, pr), pm in zip(ref.named_parameters(), mine.parameters()):
+        if id(pr) in unused and name == "adam":
+            continue  # never-touched parameters: torch skips them, the flat kernel applies its weight-decay term
+        assert (pm.detach().cpu() - pr.detach()).abs().max().item() < 2e-6, k
+    for i, p in enumerate(opt_m.flat.params):
+        assert p.grad.data_ptr() == opt_m.flat.view_of(opt_m.flat.grad, i).data_ptr()
+
+
 @pytest.mark.parametrize("dt", DTYPES, ids=IDS)
 def test_dropout_statistics_and_backward(cuda, dt):
     from video_classification_amd import ops

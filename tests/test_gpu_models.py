@@ -69,6 +69,78 @@ def test_decoder_rnn(cuda, dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES, ids=IDS)
+def test_decoder_rnn_default_embed_300(cuda, dt):
+    """The reference's constructor default CNN_embed_dim = 300 (model_components.py:199) is not a multiple of 8:
+    the LSTM input is zero-padded for the 16-byte channel groups of the bf16 GEMMs.  Against the CPU oracle."""
+    from oracle import torch_oracle as O
+    from video_classification_amd.modules import DecoderRNN
+    torch.manual_seed(11)
+    ref = O.DecoderRNN(300, 2, 64, 32, 0.0, 101)
+    mine = DecoderRNN(300, 2, 64, 32, 0.0, 101)
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    mine.to(cuda).set_compute_dtype(dt)
+    x = torch.randn(5, 6, 300, generator=torch.Generator().manual_seed(12))
+    w = torch.randn(5, 101, generator=torch.Generator().manual_seed(13))
+    xr = x.clone().requires_grad_(True)
+    ref.train()
+    outr = ref(xr)
+    (outr * w).sum().backward()
+    xm = x.to(cuda).requires_grad_(True)
+    mine.train()
+    out = mine(xm)
+    (out * w.to(cuda)).sum().backward()
+    torch.cuda.synchronize()
+    tol_o, tol_g = TOL[dt]
+    assert G.max_rel(out.detach().cpu(), outr.detach()) < tol_o
+    G.check_grads(dict(mine.named_parameters()), {k: p.grad for k, p in ref.named_parameters()}, tol_g)
+    assert tuple(xm.grad.shape) == (5, 6, 300)
+    assert G.max_rel(xm.grad.cpu(), xr.grad) < tol_g
+
+
+def test_lstm_falls_back_beside_side_stream_work(cuda, monkeypatch):
+    """While kernels of another stream may share the GPU (overlapped bucket all-reduces), a recurrence whose
+    persistent launch would need more than half of the CUs runs on the per-step kernels instead; same results."""
+    from video_classification_amd import ops
+    torch.manual_seed(2)
+    lstm = nn.LSTM(64, 512, 1, batch_first=True, bidirectional=True).to(cuda)
+    x = torch.randn(4, 96, 64, device=cuda).to(torch.bfloat16)  # [T, B, In]: 32 x 2 x 3 = 192 workgroups
+    cus = torch.cuda.get_device_properties(cuda).multi_processor_count
+    assert 192 <= cus < 384, "geometry of this test: 192 workgroups fit the CUs but are more than half of them"
+    taken = []
+    real = ops.L.call
+
+    def spy(name, *a):
+        taken.append(name)
+        return real(name, *a)
+    monkeypatch.setattr(ops.L, "call", spy)
+
+    def run(xin):
+        del taken[:]
+        xin = xin.clone().requires_grad_(True)
+        for p in lstm.parameters():
+            p.grad = None
+        y = ops.lstm(xin, lstm)
+        y.float().square().sum().backward()
+        torch.cuda.synchronize()
+        return y.detach().float(), xin.grad.float(), lstm.weight_hh_l0.grad.clone(), list(taken)
+
+    xs = x[:, :64].contiguous()   # 2 batch chunks: 128 workgroups, at most half of the CUs -> stays persistent
+    monkeypatch.setattr(ops, "SIDE_STREAM_WORK", False)
+    y0, dx0, dw0, calls0 = run(x)
+    assert "vc_lstm_persist_fwd" in calls0 and "vc_lstm_persist_bwd" in calls0
+    monkeypatch.setattr(ops, "SIDE_STREAM_WORK", True)
+    y1, dx1, dw1, calls1 = run(x)
+    assert "vc_lstm_persist_fwd" not in calls1 and "vc_lstm_persist_bwd" not in calls1
+    assert "vc_lstm_cell_fwd" in calls1 and "vc_lstm_cell_bwd" in calls1
+    _, _, _, calls2 = run(xs)
+    assert "vc_lstm_persist_fwd" in calls2
+    ops.check_lstm_error()
+    assert G.max_rel(y1.cpu(), y0.cpu()) < 2e-2
+    assert G.l2_rel(dx1.cpu(), dx0.cpu()) < 3e-2
+    assert G.l2_rel(dw1.cpu(), dw0.cpu()) < 3e-2
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=IDS)
 def test_tcg_lstm(cuda, dt):
     from video_classification_amd.modules import TCG_LSTM
     _component(cuda, "tcg_lstm_tiny", TCG_LSTM(24, 32, 2, 8, 4, 101, 0.0), ["g", "c"], dt)

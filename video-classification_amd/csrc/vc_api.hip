@@ -14,9 +14,21 @@ void vc_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// Compute units of the current device (the bound on how many one-per-CU workgroups can be resident at once);
+// 256 (MI355X) when no device can be asked, e.g. on a build host.
+int vc_device_cus() {
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      n <= 0) {
+    (void)hipGetLastError();
+    return 256;
+  }
+  return n;
+}
+
 extern "C" {
 
-int vc_version(void) { return 100; }
+int vc_version(void) { return 101; }
 
 const char* vc_last_error(void) { return g_err; }
 

@@ -30,6 +30,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 #define VC_ERR_ARG (-4)
 
 void vc_set_error(const char* fmt, ...);
+int vc_device_cus();  // compute units of the current device (256 if no device answers)
 
 #define VC_CHECK_ARG(cond, ...)        \
   do {                                 \

@@ -390,12 +390,12 @@ long long vc_lstm_persist_xchg_bytes(int B, int H) {
 }
 
 // 1 if (B, H, ndir) can run as one persistent launch: H a power of two in 32..1024 and every workgroup
-// resident at once (H/16 x ndir x ceil(B/32) <= 256 CUs).
+// resident at once (H/16 x ndir x ceil(B/32) <= the device's CU count).
 int vc_lstm_persist_supported(int dtype, int B, int H, int ndir) {
   if (dtype != VC_BF16 || B <= 0 || ndir < 1 || ndir > 2) return 0;
   if (H < 32 || H > 1024 || (H & (H - 1))) return 0;
   const long long wgs = (long long)(H / UNITS) * ndir * ((B + BCHUNK - 1) / BCHUNK);
-  return wgs <= 256 ? 1 : 0;
+  return wgs <= vc_device_cus() ? 1 : 0;
 }
 
 // All T steps of one LSTM layer, ndir directions (direction 1 runs the sequence in reverse).
@@ -443,7 +443,6 @@ int vc_lstm_persist_fwd(int dtype, const float* const* gates_x, const void* cons
   return VC_OK;
 }
 
-
 // ---- backward ----
 long long vc_lstm_persist_bwd_xchg_bytes(int B, int H) {
   const long long chunks = (B + BCHUNK - 1) / BCHUNK;
@@ -457,7 +456,7 @@ int vc_lstm_persist_bwd_supported(int dtype, int B, int H, int ndir) {
   if (dtype != VC_BF16 || B <= 0 || ndir < 1 || ndir > 2) return 0;
   if (H < 32 || H > 512 || (H & (H - 1))) return 0;
   const long long wgs = (long long)(H / UNITS) * ndir * ((B + BCHUNK - 1) / BCHUNK);
-  return wgs <= 256 ? 1 : 0;
+  return wgs <= vc_device_cus() ? 1 : 0;
 }
 
 // Backward recurrence of one LSTM layer over all T steps, ndir directions in one launch.  Per direction d:

@@ -471,13 +471,14 @@ __global__ void optim_kernel(float* __restrict__ p, const float* __restrict__ g,
   if (step_dev) step = (int)*step_dev;
   const float bc1 = 1.f - (float)pow((double)b1, (double)step);
   const float bc2_sqrt = sqrtf(1.f - (float)pow((double)b2, (double)step));
-  const int first_step = step <= 1;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     float pv = p[i];
     float gv = g[i] * grad_scale;
     if (mode == 2) {
       gv = fmaf(wd, pv, gv);
-      const float buf = first_step ? gv : fmaf(b1, m[i], gv);
+      // torch's first step sets buf = g; the buffer starts at zero, so b1 * 0 + g is the same value, and a
+      // momentum buffer restored from a checkpoint is never overwritten
+      const float buf = fmaf(b1, m[i], gv);
       m[i] = buf;
       p[i] = pv - lr * buf;
       continue;

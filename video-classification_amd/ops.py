@@ -900,6 +900,22 @@ PERSISTENT_LSTM = os.environ.get("VC_PERSISTENT_LSTM", "1") != "0"
 # VC_PERSISTENT_LSTM_BWD=0 keeps only the backward recurrence on the per-step kernels
 PERSISTENT_LSTM_BWD = os.environ.get("VC_PERSISTENT_LSTM_BWD", "1") != "0"
 _lstm_err = {}
+# True while kernels of another stream may share the GPU with the step (RCCL bucket all-reduces overlapped with
+# backward, VC_WGRAD_STREAM=1).  The persistent LSTM kernels need every one of their workgroups resident at once;
+# beside foreign workgroups that is only taken for granted while the launch fills at most half of the CUs, larger
+# launches go to the per-step kernels.
+SIDE_STREAM_WORK = False
+
+
+def lstm_persistent_allowed(query_name, code, B, H, dirs, device):
+    """Whether a layer's recurrence may run as ONE persistent launch: the shape is supported, and if other streams
+    may be active the launch leaves at least half of the CUs free."""
+    if not PERSISTENT_LSTM or L.query(query_name, code, B, H, dirs) != 1:
+        return False
+    if SIDE_STREAM_WORK or WGRAD_STREAM:
+        wgs = (H // 16) * dirs * ((B + 31) // 32)
+        return 2 * wgs <= torch.cuda.get_device_properties(device).multi_processor_count
+    return True
 
 
 def lstm_error_flag(device):
@@ -911,10 +927,14 @@ def lstm_error_flag(device):
 
 
 def check_lstm_error():
-    """Synchronising check of the persistent LSTM's error word (tests, end of an epoch)."""
+    """Synchronising check of the persistent LSTM's error word (the trainer calls it where it reads loss and
+    accuracy back anyway: every logging interval, the end of an epoch, after predictions).  The word is cleared
+    before raising, so one time-out is reported once."""
     for flag in _lstm_err.values():
         if int(flag.item()) != 0:
-            raise RuntimeError("persistent LSTM kernel: a workgroup timed out waiting for its peers; results invalid")
+            flag.zero_()
+            raise RuntimeError("persistent LSTM kernel: a workgroup timed out waiting for its peers; the results "
+                               "since the last check are invalid (VC_PERSISTENT_LSTM=0 selects the per-step kernels)")
 
 
 class _LSTM(torch.autograd.Function):
@@ -937,15 +957,18 @@ class _LSTM(torch.autograd.Function):
         saved = []
         masks = {}
         inp = x
+        if In % 8:  # the bf16 GEMMs read 16-byte channel groups: zero columns up to a multiple of 8 (W_ih is packed alike)
+            inp = torch.zeros(T, B, pad8(In), device=dev, dtype=dt)
+            inp[:, :, :In] = x
         st = L.stream()
-        persist = PERSISTENT_LSTM and L.query("vc_lstm_persist_supported", code, B, H, dirs) == 1
+        persist = lstm_persistent_allowed("vc_lstm_persist_supported", code, B, H, dirs, dev)
         for l in range(layers):
             Kin = inp.shape[-1]
             out = torch.empty(T, B, H * dirs, device=dev, dtype=dt)
             pending = []
             for d in range(dirs):
                 w_ih, w_hh, b_ih, b_hh = params[(l * dirs + d) * 4:(l * dirs + d) * 4 + 4]
-                wih_f, wih_t = _packed_weights(w_ih, Kin, 1, Kin, 4 * H, dt)
+                wih_f, wih_t = _packed_weights(w_ih, w_ih.shape[1], 1, Kin, 4 * H, dt)
                 whh_f, whh_t = _packed_weights(w_hh, H, 1, H, 4 * H, dt)
                 bsum = elementwise(0, b_ih.detach(), b_hh.detach())
                 gx = torch.empty(T, B, 4 * H, device=dev, dtype=f32)
@@ -1022,8 +1045,8 @@ class _LSTM(torch.autograd.Function):
             need_dinp = l > 0 or ctx.needs_input_grad[0]
             dinp = torch.empty(T, B, Kin, device=dev, dtype=dt) if need_dinp else None
             dgs = [torch.empty(T, B, 4 * H, device=dev, dtype=dt) for _ in range(dirs)]
-            persist = (PERSISTENT_LSTM and PERSISTENT_LSTM_BWD and
-                       L.query("vc_lstm_persist_bwd_supported", code, B, H, dirs) == 1)
+            persist = PERSISTENT_LSTM_BWD and lstm_persistent_allowed("vc_lstm_persist_bwd_supported", code, B, H,
+                                                                      dirs, dev)
             if persist:  # the recurrence of every direction of the layer as ONE persistent launch
                 import ctypes
                 nb = L.query("vc_lstm_persist_bwd_xchg_bytes", B, H)
@@ -1057,10 +1080,15 @@ class _LSTM(torch.autograd.Function):
                            L.ptr(dc[(k & 1) ^ 1]), B, H, st)
                     nxt = t
                 # weight gradients over the whole sequence
-                if w_ih.requires_grad:
+                if w_ih.requires_grad and Kin == w_ih.shape[1]:
                     # a Linear weight's packed gradient layout is the parameter's own: accumulate in place
                     L.call("vc_conv_wgrad", _lin_desc(T * B, Kin, 4 * H), code, L.ptr(inp), 0, L.ptr(dg), 0,
                            L.ptr(_grad_buf(w_ih)), L.ptr(None), 0, st)
+                elif w_ih.requires_grad:  # zero-padded input columns: packed rows are longer than the parameter's
+                    dwp = _wgrad_scratch(w_ih, (4 * H, 1, Kin))
+                    L.call("vc_conv_wgrad", _lin_desc(T * B, Kin, 4 * H), code, L.ptr(inp), 0, L.ptr(dg), 0,
+                           L.ptr(dwp), L.ptr(None), 0, st)
+                    L.call("vc_unpack_wgrad", L.ptr(dwp), L.ptr(_grad_buf(w_ih)), 4 * H, w_ih.shape[1], 1, Kin, 3, st)
                 if w_hh.requires_grad and T > 1:
                     # pairs (h_prev, dgates_t): forward dir h[0..T-2] with dg[1..T-1]; reverse dir h[1..T-1] with dg[0..T-2]
                     h_off = 0 if d == 0 else 1
@@ -1073,9 +1101,13 @@ class _LSTM(torch.autograd.Function):
                         L.call("vc_colsum", code, L.ptr(dg), L.ptr(_grad_buf(b_)), T * B, 4 * H, 4 * H, st)
                 _ready(w_ih, w_hh, b_ih, b_hh)
                 if need_dinp:
-                    L.call("vc_conv_dgrad", _lin_desc(T * B, Kin, 4 * H), code, L.ptr(dg), 0, L.ptr(wih_t),
-                           L.ptr(dinp), 0, int(dt == torch.float32), int(d > 0), st)
+                    # the transposed pack has one row per TRUE input column: the padded columns of dinp (rows are Kin
+                    # wide) are left unwritten and sliced off below
+                    L.call("vc_conv_dgrad", _lin_desc(T * B, w_ih.shape[1], 4 * H), code, L.ptr(dg), 0, L.ptr(wih_t),
+                           L.ptr(dinp), Kin, int(dt == torch.float32), int(d > 0), st)
             dlayer = dinp
+            if l == 0 and dinp is not None and Kin != In:
+                dlayer = dinp[:, :, :In].contiguous()
             if l > 0 and (l - 1) in ctx.masks:
                 dlayer = torch.empty_like(dinp)
                 L.call("vc_dropout_bwd", code, L.ptr(dinp), L.ptr(ctx.masks[l - 1]), L.ptr(dlayer), L.i64(dinp.numel()),

@@ -102,8 +102,23 @@ class FusedOptimizer(torch.optim.Optimizer):
         if self.bucketer is not None:
             self.bucketer.reset()
 
+    def _attach_grads(self):
+        """Every parameter's .grad must be its slice of the flat gradient buffer (the kernels accumulate there and
+        the fused step reads the flat buffer).  A caller's ``model.zero_grad()`` with set_to_none detaches them; a
+        gradient that then got allocated elsewhere is moved back, a missing one reads as zero."""
+        flat = self.flat
+        for i, p in enumerate(flat.params):
+            view = flat.view_of(flat.grad, i)
+            g = p.grad
+            if g is None:
+                p.grad = view
+            elif g.data_ptr() != view.data_ptr():
+                view.copy_(g)
+                p.grad = view
+
     @torch.no_grad()
     def step(self, closure=None):
+        self._attach_grads()
         if self.bucketer is not None:
             self.bucketer.finish()
         self.sync_lr()
@@ -113,12 +128,13 @@ class FusedOptimizer(torch.optim.Optimizer):
     def launch(self):
         """Enqueue the kernels of one optimizer step (no host-side bookkeeping; graph-capturable)."""
         g = self.param_groups[0]
-        b1, b2 = g["betas"]
+        # a state_dict written by torch.optim carries only that optimizer's own hyper-parameters
+        b1, b2 = g.get("betas", (0.9, 0.999))
         if self.mode == 2:
-            b1 = g["momentum"]
+            b1 = g.get("momentum", 0.9)
         L.call("vc_counter_add", L.ptr(self.step_dev), L.i64(1), L.stream())
         L.call("vc_optim_step", self.mode, L.ptr(self.flat.data), L.ptr(self.flat.grad), L.ptr(self.m), L.ptr(self.v),
-               L.i64(self.flat.total), float(g["lr"]), float(b1), float(b2), float(g["eps"]),
+               L.i64(self.flat.total), float(g["lr"]), float(b1), float(b2), float(g.get("eps", 1e-8)),
                float(g["weight_decay"]), 0, float(self.grad_scale), L.ptr(self.lr_dev), L.ptr(self.step_dev),
                L.stream())
         ops.advance_seed_counter(self.flat.data.device)
@@ -140,17 +156,31 @@ class FusedOptimizer(torch.optim.Optimizer):
 
     def load_state_dict(self, state_dict):
         # torch re-creates the state tensors; copy them back into the flat buffers
+        # A torch.optim checkpoint carries no state for a parameter that never received a gradient (and SGD state
+        # has no step count at all): such moments are zero, which is what the flat buffers are set to.
         super().load_state_dict(state_dict)
+        steps = 0
         for i, p in enumerate(self.flat.params):
             st = self.state[p]
+            mv = self.flat.view_of(self.m, i)
             if self.mode == 2:
-                self.flat.view_of(self.m, i).copy_(st["momentum_buffer"])
-                st["momentum_buffer"] = self.flat.view_of(self.m, i)
+                buf = st.get("momentum_buffer")
+                mv.copy_(buf) if buf is not None else mv.zero_()
+                st["momentum_buffer"] = mv
             else:
-                self.flat.view_of(self.m, i).copy_(st["exp_avg"])
-                self.flat.view_of(self.v, i).copy_(st["exp_avg_sq"])
-                st["exp_avg"], st["exp_avg_sq"] = self.flat.view_of(self.m, i), self.flat.view_of(self.v, i)
-                self.steps = int(st["step"])
+                vv = self.flat.view_of(self.v, i)
+                mv.copy_(st["exp_avg"]) if "exp_avg" in st else mv.zero_()
+                vv.copy_(st["exp_avg_sq"]) if "exp_avg_sq" in st else vv.zero_()
+                st["exp_avg"], st["exp_avg_sq"] = mv, vv
+                if "step" in st:
+                    steps = max(steps, int(st["step"]))
+                else:
+                    st["step"] = torch.tensor(0.0)
+        if self.mode != 2:
+            # one shared step count drives the bias correction of the fused kernel
+            self.steps = steps
+            for p in self.flat.params:
+                self.state[p]["step"] = torch.tensor(float(steps))
         self.step_dev.fill_(self.steps)
         self._lr_host = None
         self.sync_lr()
@@ -305,6 +335,7 @@ def make_data_parallel(model, optimizer, bucket_mb=32, group=None, overlap=True)
     optimizer.bucketer = bucketer
     optimizer.grad_scale = 1.0 / world
     ops.set_grad_ready_hook(bucketer.notify)
+    ops.SIDE_STREAM_WORK = world > 1 and bucketer.overlap
     return bucketer
 
 
@@ -357,7 +388,10 @@ def train_epoch(model, train_loader, criterion, optimizer, device, epoch, use_am
         if logger and (batch_idx + 1) % 100 == 0:
             logger.info(f"Epoch {epoch} - Batch {batch_idx + 1}/{len(train_loader)} - Loss: {loss.item():.4f}, "
                         f"Acc: {100. * correct.item() / total:.2f}%")
-    return total_loss.item() / max(nb, 1), 100. * correct.item() / max(total, 1)
+            ops.check_lstm_error()  # the stream was just synchronised by .item(): the read costs nothing more
+    result = total_loss.item() / max(nb, 1), 100. * correct.item() / max(total, 1)
+    ops.check_lstm_error()
+    return result
 
 
 def validate_epoch(model, val_loader, criterion, device, epoch, use_amp=False, logger=None):
@@ -377,7 +411,9 @@ def validate_epoch(model, val_loader, criterion, device, epoch, use_amp=False, l
             if logger and (batch_idx + 1) % 50 == 0:
                 logger.info(f"Epoch {epoch} - Val Batch {batch_idx + 1}/{len(val_loader)} - Loss: {loss.item():.4f}, "
                             f"Acc: {100. * correct.item() / total:.2f}%")
-    return total_loss.item() / max(nb, 1), 100. * correct.item() / max(total, 1)
+    result = total_loss.item() / max(nb, 1), 100. * correct.item() / max(total, 1)
+    ops.check_lstm_error()
+    return result
 
 
 def save_checkpoint(model, optimizer, epoch, loss, save_path, scheduler=None):
@@ -484,7 +520,9 @@ def predict_topk(model, clip, k=5):
         probs = torch.softmax(logits.float(), dim=1)[0]
     k = min(k, probs.numel())
     p, idx = torch.sort(probs, descending=True, stable=True)
-    return p[:k].cpu(), idx[:k].cpu()
+    p, idx = p[:k].cpu(), idx[:k].cpu()
+    ops.check_lstm_error()
+    return p, idx
 
 
 def save_predictions(model, test_loader, device, save_path, action_names=None):
@@ -504,6 +542,7 @@ def save_predictions(model, test_loader, device, save_path, action_names=None):
             labels.append(target.reshape(-1))
     y_pred = torch.cat(preds).cpu().numpy().flatten() if preds else []
     y = torch.cat(labels).cpu().numpy().flatten() if labels else []
+    ops.check_lstm_error()
     results_df = pd.DataFrame({"y": y, "y_pred": y_pred})
     if not (dist.is_initialized() and dist.get_rank() != 0):
         os.makedirs(os.path.dirname(save_path) or ".", exist_ok=True)
