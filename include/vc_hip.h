@@ -231,6 +231,16 @@ int vc_lstm_persist_supported(int dtype, int B, int H, int ndir);
 int vc_lstm_persist_fwd(int dtype, const float* const* gates_x, const void* const* w_hh, void* const* hs, int ldh,
                         float* const* act, float* const* c, void* const* xchg, int* err, int T, int B, int H,
                         int ndir, vc_stream_t stream);
+/* No counterpart in the reference.  vc_lstm_persist_fwd for callers that cannot allocate device memory (code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): same arguments without xchg; the exchange
+ * buffer is a 512 KiB array inside the library's code object (one copy per GPU, held until the process ends), and the
+ * call allocates and frees nothing.  Refused (VC_ERR_SHAPE) when ndir * ceil(B/32) * H * 256 bytes exceed 512 KiB
+ * (both directions of B <= 64 at H = 512, or of B <= 32 at H = 1024, fit).
+ * All calls on one GPU share that GPU's array: calls that overlap in time on one GPU race; calls on one stream are
+ * ordered, and each clears what the one before left. */
+int vc_lstm_persist_fwd_noalloc(int dtype, const float* const* gates_x, const void* const* w_hh, void* const* hs,
+                                int ldh, float* const* act, float* const* c, int* err, int T, int B, int H, int ndir,
+                                vc_stream_t stream);
 /* Backward recurrence (BPTT) of the same layer in one persistent launch: per direction dh_out (bf16, gradient of the
  * layer output at dh_out[(t*B + b)*ldo + j]), act / c as saved by the forward pass, w_hh_t = W_hh^T [H][4H] bf16 held in
  * registers, dgates [T][B][4H] bf16 receives the gate pre-activation gradients of every step (what the sequence-wide

@@ -14,6 +14,8 @@
 //   B cols  = 16 batch rows (two tiles cover the 32 rows a workgroup handles)
 //   D[row = 4*(lane>>4) + r][col = lane&15]  ->  lane holds gates r = 0..3 (i, f, g, o) of
 //   unit 4w + (lane>>4) for batch row (lane&15) + 16*tile.
+#include <mutex>
+
 #include "vc_common.h"
 
 namespace {
@@ -364,6 +366,38 @@ __global__ __launch_bounds__(LTHR, 1) void lstm_persist_bwd_kernel(LstmBwdArgs a
   }
 }
 
+// Exchange buffer of the entry point that allocates nothing (vc_lstm_persist_fwd_noalloc): it lives in the code
+// object, one copy per GPU the library runs on, held until the process ends.  Host code never uses the array's name
+// as an address: the per-device address comes from hipGetSymbolAddress (scratch_ptr below).
+constexpr size_t SCRATCH_BYTES = 512u << 10;  // e.g. both directions of B <= 64, H = 512 or of B <= 32, H = 1024
+static __device__ __align__(256) __attribute__((used)) unsigned char scratch[SCRATCH_BYTES];
+
+constexpr int MAX_DEVICES = 64;
+void* g_scratch_ptr[MAX_DEVICES];  // zero-initialised; written once per device
+std::mutex g_scratch_mutex;
+
+// Device address of `scratch` on the current device (looked up once per device, with that device current).
+int scratch_ptr(void** out) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) {
+    vc_set_error("vc_lstm_persist_fwd_noalloc: no usable current device (hipGetDevice gave %d)", dev);
+    return VC_ERR_HIP;
+  }
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[dev]) {
+    void* p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !p) {
+      vc_set_error("vc_lstm_persist_fwd_noalloc: hipGetSymbolAddress failed on device %d: %s", dev,
+                   hipGetErrorString(e));
+      return VC_ERR_HIP;
+    }
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return VC_OK;
+}
+
 template <int NKS>
 int launch_lstm_bwd(const LstmBwdArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
   static bool attr_set = false;  // > 64 KB of dynamic LDS has to be allowed once per kernel
@@ -441,6 +475,29 @@ int vc_lstm_persist_fwd(int dtype, const float* const* gates_x, const void* cons
   }
   VC_LAUNCH_CHECK("vc_lstm_persist_fwd");
   return VC_OK;
+}
+
+// vc_lstm_persist_fwd for callers that cannot allocate device memory (code under HIP graph capture, serving loops,
+// harnesses that forbid hipMalloc): the exchange buffer is the library's own `scratch` array instead of a caller
+// buffer; the call allocates and frees nothing.  Shapes whose exchange needs more than the array holds
+// (ndir * ceil(B/32) * H * 256 bytes > 512 KiB) are refused.  Every call on a GPU uses that GPU's one array: calls
+// that overlap in time on one GPU (two streams) race; calls on one stream are ordered and each clears the tags
+// of the one before.
+int vc_lstm_persist_fwd_noalloc(int dtype, const float* const* gates_x, const void* const* w_hh, void* const* hs,
+                                int ldh, float* const* act, float* const* c, int* err, int T, int B, int H, int ndir,
+                                hipStream_t stream) {
+  VC_CHECK_SHAPE(vc_lstm_persist_supported(dtype, B, H, ndir),
+                 "vc_lstm_persist_fwd_noalloc: unsupported shape B=%d H=%d ndir=%d (ask vc_lstm_persist_supported)", B,
+                 H, ndir);
+  const long long per_dir = vc_lstm_persist_xchg_bytes(B, H);
+  VC_CHECK_SHAPE(per_dir * ndir <= (long long)SCRATCH_BYTES,
+                 "vc_lstm_persist_fwd_noalloc: B=%d H=%d ndir=%d needs %lld bytes of exchange buffer, the built-in one "
+                 "holds %zu; use vc_lstm_persist_fwd with a caller buffer", B, H, ndir, per_dir * ndir, SCRATCH_BYTES);
+  void* base = nullptr;
+  const int rc = scratch_ptr(&base);
+  if (rc) return rc;
+  void* xchg[2] = {base, static_cast<unsigned char*>(base) + per_dir};
+  return vc_lstm_persist_fwd(dtype, gates_x, w_hh, hs, ldh, act, c, xchg, err, T, B, H, ndir, stream);
 }
 
 // ---- backward ----
