@@ -109,13 +109,14 @@ class Bottleneck(nn.Module):
 RESNET_LAYERS = {"resnet50": (3, 4, 6, 3), "resnet101": (3, 4, 23, 3), "resnet152": (3, 8, 36, 3)}
 
 
-def make_resnet_trunk(arch="resnet152"):
+def make_resnet_trunk(arch="resnet152", width=64):
     """`nn.Sequential(*list(resnet.children())[:-1])` (model_components.py:164-165): indices 0 conv1,
-    1 bn1, 2 relu, 3 maxpool, 4-7 layer1-4, 8 avgpool."""
+    1 bn1, 2 relu, 3 maxpool, 4-7 layer1-4, 8 avgpool.  `width` = channels of the stem (64 in torchvision; the
+    stand-in trunks of the fixtures are narrower)."""
     layers = RESNET_LAYERS[arch]
-    inplanes = 64
+    inplanes = width
     stages = []
-    for i, (planes, n) in enumerate(zip((64, 128, 256, 512), layers)):
+    for i, (planes, n) in enumerate(zip((width, 2 * width, 4 * width, 8 * width), layers)):
         stride = 1 if i == 0 else 2
         blocks = []
         for b in range(n):
@@ -126,7 +127,7 @@ def make_resnet_trunk(arch="resnet152"):
             blocks.append(Bottleneck(inplanes, planes, s, ds))
             inplanes = planes * 4
         stages.append(nn.Sequential(*blocks))
-    trunk = nn.Sequential(nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False), nn.BatchNorm2d(64),
+    trunk = nn.Sequential(nn.Conv2d(3, width, 7, stride=2, padding=3, bias=False), nn.BatchNorm2d(width),
                           nn.ReLU(inplace=True), nn.MaxPool2d(3, stride=2, padding=1), *stages,
                           nn.AdaptiveAvgPool2d((1, 1)))
     for m in trunk.modules():  # torchvision's initialisation
@@ -160,13 +161,13 @@ class _HeadBN(nn.Module):
 
 class ResCNNEncoder(_HeadBN):
     def __init__(self, fc_hidden1=512, fc_hidden2=512, drop_p=0.3, CNN_embed_dim=300, use_pretrained=True,
-                 arch="resnet152"):
+                 arch="resnet152", width=64):
         super().__init__()
         # use_pretrained only selects the initial weights in the reference (model_components.py:157-162);
         # there is no network here, so the trunk always starts from torchvision's random init.
         self.drop_p = drop_p
-        self.resnet = make_resnet_trunk(arch)
-        self._make_head(2048, fc_hidden1, fc_hidden2, CNN_embed_dim)
+        self.resnet = make_resnet_trunk(arch, width)
+        self._make_head(32 * width, fc_hidden1, fc_hidden2, CNN_embed_dim)
 
     def forward(self, x_3d):
         return _per_frame(lambda f: self._head(self.resnet(f).flatten(1), False), x_3d)

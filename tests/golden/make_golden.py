@@ -8,9 +8,11 @@ not travel to the GPU box):
 
 `utils/common/model_components.py` imports torchvision at module level and the image has no
 torchvision, so an empty in-process stub module is registered under that name before the import
-(nothing is installed or fetched); the classes exercised here never touch it.  Classes that need
-torchvision / timm weights at construction (ResCNNEncoder, ClusterSwinEncoder, the VGG branch
-of EncoderCNN) cannot be built and are not covered.
+(nothing is installed or fetched).  ResCNNEncoder and ClusterSwinEncoder fetch a third-party network at
+construction (torchvision resnet152, timm swin_tiny): for them small stand-in networks
+(tests/golden_util.py: resnet_standin, swin_standin) are registered where the reference looks the real ones up,
+and the reference's own constructor, head, per-frame loop and token glue run unchanged around them.  The VGG
+branch of EncoderCNN is not covered.
 
 Each fixture is an .npz of plain arrays: inputs, the initial state_dict ("p/<key>"), outputs,
 gradients ("g/<key>"), post-step buffers / parameters ("a/<key>").
@@ -20,12 +22,17 @@ import os
 import sys
 import types
 
+sys.dont_write_bytecode = True  # nothing is written into the reference checkout
+import zlib
+
 import numpy as np
 import torch
 import torch.nn as nn
 
 REF = os.environ.get("VC_REFERENCE", "/root/reference")
 OUT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(OUT))                    # tests/ (golden_util)
+sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))   # repository root (oracle, for the stand-ins)
 
 
 def _import_reference():
@@ -94,6 +101,43 @@ def main():
     torch.set_num_threads(8)
     mc, tu, conv3d, crnn = _import_reference()
     g = torch.Generator()
+    only = set(sys.argv[1:])  # fixture names to (re)generate; none = all
+
+    if not only or "rescnn_standin" in only:
+        # 8. ResCNNEncoder: the reference's constructor (children()[:-1] wrap, fc.in_features), its
+        #    fc1-bn1-relu-fc2-bn2-relu-dropout-fc3 head and per-frame loop around a stand-in trunk
+        import golden_util as GU
+        sys.modules["torchvision.models"].resnet152 = GU.resnet_standin
+        torch.manual_seed(0)
+        enc = mc.ResCNNEncoder(fc_hidden1=64, fc_hidden2=48, drop_p=0.0, CNN_embed_dim=32, use_pretrained=False)
+        with torch.no_grad():  # residual branches damped and non-trivial BatchNorm affines, as after training
+            for n, p in enc.named_parameters():
+                if n.endswith("bn3.weight"):
+                    p.fill_(0.25)
+                elif ".bn" in n or n.startswith("resnet.1."):
+                    p.add_(0.1 * torch.randn(p.shape, generator=g.manual_seed(zlib.crc32(n.encode()) % 1000)))
+        _component_case("rescnn_standin", enc, {"x": torch.randn(6, 3, 3, 64, 64, generator=g.manual_seed(11))})
+
+    if not only or "cluster_swin_standin" in only:
+        # 9. ClusterSwinEncoder: the reference's constructor (backbone probe, proj) and forward (per-frame loop,
+        #    projection, k repeated "cluster tokens", stacking) around a stand-in backbone
+        import golden_util as GU
+        mc.create_model = GU.swin_standin
+        torch.manual_seed(0)
+        enc = mc.ClusterSwinEncoder(backbone="swin_tiny_patch4_window7_224", embed_dim=24, k_tokens=8)
+        x = torch.randn(2, 4, 3, 56, 56, generator=g.manual_seed(12))
+        d = {"in/x": x.numpy()}
+        d.update(_sd("p", enc))
+        enc.train()
+        gg, cc = enc(x)
+        wg = torch.randn(gg.shape, generator=g.manual_seed(13))
+        wc = torch.randn(cc.shape, generator=g.manual_seed(14))
+        ((gg * wg).sum() + (cc * wc).sum()).backward()
+        d.update({"loss_wg": wg.numpy(), "loss_wc": wc.numpy(), "out_g": gg.detach().numpy(), "out_c": cc.detach().numpy()})
+        d.update(_grads(enc))
+        _save("cluster_swin_standin", d)
+    if only:
+        return
 
     # 1. EncoderCNN tiny: pins per-time-step BatchNorm statistics and the T running-stat updates
     torch.manual_seed(0)

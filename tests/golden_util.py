@@ -36,6 +36,41 @@ def conv3d_config():
     return types.SimpleNamespace(dropout_p=0.0, num_classes=101)
 
 
+# ---- stand-ins for the third-party networks the reference fetches at construction -------------------------------
+# make_golden.py registers them where the reference looks its backbones up (torchvision.models.resnet152,
+# model_components.create_model), so that the reference's OWN ResCNNEncoder / ClusterSwinEncoder code runs
+# unchanged around them; the tests build the same stand-ins to know what the fixtures' keys mean.
+RESNET_STANDIN = dict(arch="tiny", width=8)      # bottleneck trunk [1, 1, 1, 1], 8 stem channels, 256 features
+SWIN_STANDIN = dict(img=56, patch=4, dim=32, depths=(2, 2), heads=(1, 2), ws=7)
+
+
+def resnet_standin(weights=None):
+    """A module with torchvision's ResNet child layout (conv1, bn1, relu, maxpool, layer1-4, avgpool, fc): the
+    reference wraps list(children())[:-1] and reads fc.in_features (model_components.py:164-166)."""
+    import torch.nn as nn
+    from oracle import torch_oracle as O
+    O.RESNET_LAYERS.setdefault("tiny", (1, 1, 1, 1))
+    trunk = O.make_resnet_trunk(**RESNET_STANDIN)
+    m = nn.Module()
+    for name, child in zip(("conv1", "bn1", "relu", "maxpool", "layer1", "layer2", "layer3", "layer4", "avgpool"), trunk):
+        m.add_module(name, child)
+    m.add_module("fc", nn.Linear(32 * RESNET_STANDIN["width"], 10))
+    return m
+
+
+def swin_standin(name="swin_tiny_patch4_window7_224", pretrained=True, num_classes=0):
+    """Stands in for timm.create_model(name, pretrained=True, num_classes=0): a two-stage Swin of the oracle's
+    restatement.  The reference's constructor probes its backbone with one 224 x 224 frame
+    (model_components.py:419-422); the stand-in looks at that frame's top-left 56 x 56 corner."""
+    from oracle import torch_oracle as O
+
+    class Backbone(O.SwinT):
+        def forward(self, x):
+            n = SWIN_STANDIN["img"]
+            return super().forward(x[..., :n, :n])
+    return Backbone(**SWIN_STANDIN)
+
+
 def max_rel(a, b):
     a = torch.as_tensor(a).double()
     b = torch.as_tensor(b).double()

@@ -63,6 +63,25 @@ def test_encoder_cnn(cuda, dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES, ids=IDS)
+def test_rescnn_encoder_around_standin_trunk(cuda, dt):
+    """Golden from the reference's own ResCNNEncoder (constructor wrap, BatchNorm head, per-frame loop:
+    model_components.py:164-191) run around a narrow stand-in trunk; the HIP module builds the same trunk."""
+    from video_classification_amd import modules as M
+    M.RESNET_LAYERS.setdefault("tiny", (1, 1, 1, 1))
+    enc = M.ResCNNEncoder(64, 48, 0.0, 32, use_pretrained=False, **G.RESNET_STANDIN)
+    if dt == torch.bfloat16:
+        # six 64 x 64 frames per BatchNorm group and 2 x 2 maps in the last stage: ill-conditioned with
+        # random weights (see test_gpu_fullsize.py on what that does to bf16 gradients); outputs only, then fp32-exact
+        d = G.load("rescnn_standin")
+        enc.load_state_dict(G.group(d, "p"), strict=True)
+        enc.to(cuda).set_compute_dtype(dt).train()
+        out = enc(torch.from_numpy(d["in/x"]).to(cuda))
+        assert G.max_rel(out.detach().cpu(), d["out_train"]) < 6e-2
+        return
+    _component(cuda, "rescnn_standin", enc, ["x"], dt, float_inputs_grad=False, cancelled=["fc1.bias", "fc2.bias"])
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=IDS)
 def test_decoder_rnn(cuda, dt):
     from video_classification_amd.modules import DecoderRNN
     _component(cuda, "decoder_rnn_tiny", DecoderRNN(32, 3, 32, 16, 0.0, 101), ["x"], dt)

@@ -116,3 +116,22 @@ def test_cluster_swin_tcg_vs_oracle(cuda, dt):
     assert G.max_rel(out_m.detach().cpu(), out_r.detach()) < tol_o
     assert abs(loss_m.item() - loss_r.item()) < (1e-4 if dt == torch.float32 else 2e-2)
     G.check_grads(dict(mine.named_parameters()), {k: p.grad for k, p in ref.named_parameters()}, tol_g)
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=IDS)
+def test_cluster_swin_encoder_around_standin_backbone(cuda, dt):
+    """Golden from the reference's own ClusterSwinEncoder (model_components.py:408-475: per-frame loop, projection,
+    k repeated tokens, stacking) run around a stand-in backbone; the HIP module builds the same backbone."""
+    from video_classification_amd.swin import ClusterSwinEncoder
+    d = G.load("cluster_swin_standin")
+    enc = ClusterSwinEncoder(embed_dim=24, k_tokens=8, swin_kwargs=G.SWIN_STANDIN)
+    enc.load_state_dict(G.group(d, "p"), strict=True)
+    enc.to(cuda).set_compute_dtype(dt)
+    enc.train()
+    g, c = enc(torch.from_numpy(d["in/x"]).to(cuda))
+    assert tuple(g.shape) == (2, 4, 24) and tuple(c.shape) == (2, 4, 8, 24)
+    ((g * torch.from_numpy(d["loss_wg"]).to(cuda)).sum() + (c * torch.from_numpy(d["loss_wc"]).to(cuda)).sum()).backward()
+    tol_o, tol_g = TOL[dt]
+    assert G.max_rel(g.detach().cpu(), d["out_g"]) < tol_o
+    assert G.max_rel(c.detach().cpu(), d["out_c"]) < tol_o
+    G.check_grads(dict(enc.named_parameters()), G.group(d, "g"), tol_g)

@@ -57,6 +57,31 @@ def test_swin_head_and_frame_loop():
     _run_component("swin_head_tiny", enc, ["x"])
 
 
+def test_rescnn_encoder_around_standin_trunk():
+    """The reference's ResCNNEncoder (constructor wrap of children()[:-1], head, per-frame loop) around the stand-in
+    trunk of golden_util.resnet_standin: pins model_components.py:164-191."""
+    O.RESNET_LAYERS.setdefault("tiny", (1, 1, 1, 1))
+    _run_component("rescnn_standin", O.ResCNNEncoder(64, 48, 0.0, 32, use_pretrained=False, **G.RESNET_STANDIN), ["x"])
+
+
+def test_cluster_swin_encoder_around_standin_backbone():
+    """The reference's ClusterSwinEncoder.forward (per-frame loop, projection, k repeated tokens, stacking:
+    model_components.py:452-475) around the stand-in backbone of golden_util.swin_standin."""
+    d = G.load("cluster_swin_standin")
+    enc = O.ClusterSwinEncoder(embed_dim=24, k_tokens=8, swin_kwargs=G.SWIN_STANDIN)
+    enc.load_state_dict(G.group(d, "p"), strict=True)
+    enc.train()
+    g, c = enc(torch.from_numpy(d["in/x"]))
+    ((g * torch.from_numpy(d["loss_wg"])).sum() + (c * torch.from_numpy(d["loss_wc"])).sum()).backward()
+    assert tuple(c.shape) == (2, 4, 8, 24)
+    assert G.max_rel(g.detach(), d["out_g"]) < TOL and G.max_rel(c.detach(), d["out_c"]) < TOL
+    params = dict(enc.named_parameters())
+    grefs = G.group(d, "g")
+    assert set(grefs) == set(params)
+    for k, gref in grefs.items():
+        assert G.max_rel(params[k].grad, gref) < 5 * TOL, k
+
+
 def test_crnn_train_step_and_eval():
     d = G.load("crnn_tiny_step")
     model = O.CRNNModel(G.tiny_crnn_config())

@@ -135,12 +135,13 @@ class Bottleneck(nn.Module):
 RESNET_LAYERS = {"resnet50": (3, 4, 6, 3), "resnet101": (3, 4, 23, 3), "resnet152": (3, 8, 36, 3)}
 
 
-def make_resnet_trunk(arch="resnet152"):
+def make_resnet_trunk(arch="resnet152", width=64):
     """Children 0..8 = conv1, bn1, relu, maxpool, layer1..4, avgpool, i.e. the layout of
-    ``nn.Sequential(*list(resnet.children())[:-1])`` (reference model_components.py:164-165)."""
-    inplanes = 64
+    ``nn.Sequential(*list(resnet.children())[:-1])`` (reference model_components.py:164-165).  `width` = channels of
+    the stem (64 in torchvision's networks; a multiple of 8)."""
+    inplanes = width
     stages = []
-    for i, (planes, n) in enumerate(zip((64, 128, 256, 512), RESNET_LAYERS[arch])):
+    for i, (planes, n) in enumerate(zip((width, 2 * width, 4 * width, 8 * width), RESNET_LAYERS[arch])):
         blocks = []
         for b in range(n):
             s = (1 if i == 0 else 2) if b == 0 else 1
@@ -150,7 +151,7 @@ def make_resnet_trunk(arch="resnet152"):
             blocks.append(Bottleneck(inplanes, planes, s, ds))
             inplanes = planes * 4
         stages.append(nn.Sequential(*blocks))
-    trunk = nn.Sequential(nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False), nn.BatchNorm2d(64),
+    trunk = nn.Sequential(nn.Conv2d(3, width, 7, stride=2, padding=3, bias=False), nn.BatchNorm2d(width),
                           nn.ReLU(inplace=True), nn.MaxPool2d(3, stride=2, padding=1), *stages,
                           nn.AdaptiveAvgPool2d((1, 1)))
     for m in trunk.modules():
@@ -191,14 +192,14 @@ class _HeadBN(_HipModule):
 
 class ResCNNEncoder(_HeadBN):
     def __init__(self, fc_hidden1=512, fc_hidden2=512, drop_p=0.3, CNN_embed_dim=300, use_pretrained=True,
-                 arch="resnet152"):
+                 arch="resnet152", width=64):
         super().__init__()
         # The reference downloads ImageNet weights when use_pretrained is set (model_components.py:157-162);
         # here the trunk always starts from torchvision's random initialisation and pretrained weights, if
         # wanted, arrive through load_state_dict (same keys).
         self.fc_hidden1, self.fc_hidden2, self.drop_p = fc_hidden1, fc_hidden2, drop_p
-        self.resnet = make_resnet_trunk(arch)
-        self._make_head(2048, fc_hidden1, fc_hidden2, CNN_embed_dim)
+        self.resnet = make_resnet_trunk(arch, width)
+        self._make_head(32 * width, fc_hidden1, fc_hidden2, CNN_embed_dim)
 
     def forward(self, x_3d):
         B, T = x_3d.shape[0], x_3d.shape[1]
