@@ -3,13 +3,17 @@
 A training step of these models is 1.5-3 thousand kernel launches; issued one by one from Python the host,
 not the GPU, sets the step time for the smaller workloads (Swin at 8 clips: 33 ms of kernels in a 61 ms step).
 ``GraphedTrainStep`` records zero-grad + forward + loss + backward (+ the fused optimizer when there is a single
-rank) once into a graph over static input buffers and replays it per batch.  Everything that changes from step
-to step is read from device memory by the kernels (optimizer step count and learning rate, dropout seed
-counter), so the replayed graph stays correct.
+rank) once over static input buffers and replays it per batch.  Everything that changes from step to step is read
+from device memory by the kernels (optimizer step count and learning rate, dropout seed counter), so the replayed
+graphs stay correct.
 
-With more than one rank the gradient all-reduce and the optimizer stay outside the graph: the buckets are
-reduced right after the replay (102 MB of fp32 gradients for ResNet-50 is ~2 ms on xGMI next to a ~75 ms step),
-then the optimizer kernel runs.
+The backward pass is captured in PHASES, one hipGraph each, cut at the activations the encoders mark at their stage
+boundaries (``ops.mark_cut``): phase 0 = zero-grad, forward, loss and the backward pass down to the last mark, phase k
+= the backward pass between two marks, the last phase = the rest (and the optimizer when there is one rank).  With more
+than one rank the gradient buckets whose parameters a phase has completed are all-reduced (RCCL, side stream) while the
+next phase replays, so the exchange overlaps the backward pass as it does in the eager executor; the optimizer kernel
+is launched after the last bucket has arrived.  Collectives themselves are issued from the host between replays, not
+captured.
 """
 import torch
 import torch.distributed as dist
@@ -18,7 +22,7 @@ from . import ops
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, criterion, x_example, y_example, warmup=3):
+    def __init__(self, model, optimizer, criterion, x_example, y_example, warmup=3, phased=True):
         self.model, self.opt, self.crit = model, optimizer, criterion
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.x = x_example.clone()
@@ -34,20 +38,59 @@ class GraphedTrainStep:
                 self._eager()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        ops.set_grad_ready_hook(None)  # no collectives inside the capture
+        # no collectives inside the capture: the hook only notes in which phase a parameter's gradient is complete
+        phase_of = {}
+        cur = [0]
+        ops.set_grad_ready_hook(lambda p: phase_of.__setitem__(id(p), cur[0]))
+        ops._cut_recorder = [] if phased else None
+        self.graphs = []
         try:
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            g0 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g0):
                 self.opt.flat.zero_grad()
                 out = model(self.x)
                 self.loss = criterion(out, self.y)
-                self.loss.backward()
-                if self.world == 1:
-                    self.opt.launch()
+                cuts, ops._cut_recorder = (ops._cut_recorder or []), None
+                if cuts:
+                    grad = torch.autograd.grad([self.loss], [cuts[-1]])[0]
+                else:
+                    self.loss.backward()
+                    if self.world == 1:
+                        self.opt.launch()
+            self.graphs.append(g0)
+            for k in range(len(cuts) - 1, -1, -1):
+                cur[0] += 1
+                gk = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gk, pool=g0.pool()):  # one memory pool: activations of phase 0 are freed here
+                    if k > 0:
+                        grad = torch.autograd.grad([cuts[k]], [cuts[k - 1]], [grad])[0]
+                    else:
+                        torch.autograd.backward([cuts[0]], [grad])
+                        if self.world == 1:
+                            self.opt.launch()
+                self.graphs.append(gk)
             self.out = out
         finally:
+            ops._cut_recorder = None
             ops.set_grad_ready_hook(hook)
+        del cuts
+        # buckets to reduce after each phase: a bucket is complete once its last parameter is (parameters that no
+        # kernel reported -- none today -- count as complete at the very end)
+        self.phase_buckets = [[] for _ in self.graphs]
+        b = self.opt.bucketer
+        if b is not None:
+            last = len(self.graphs) - 1
+            done = [0] * len(b.buckets)
+            for p in self.opt.flat.params:
+                i = b.bucket_of[id(p)]
+                done[i] = max(done[i], phase_of.get(id(p), last))
+            for i, ph in enumerate(done):
+                self.phase_buckets[ph].append(i)
         ops.bump_weights_epoch()
+
+    @property
+    def graph(self):  # the single graph of an unphased step (kept for callers that replay it themselves)
+        return self.graphs[0]
 
     def _eager(self):
         self.opt.zero_grad()
@@ -63,11 +106,16 @@ class GraphedTrainStep:
         if y is not self.y:
             self.y.copy_(y, non_blocking=True)
         self.opt.sync_lr()
-        self.graph.replay()
-        if self.world > 1:
-            b = self.opt.bucketer
+        b = self.opt.bucketer if self.world > 1 else None
+        if b is not None:
+            b.reset()
+        for g, buckets in zip(self.graphs, self.phase_buckets):
+            g.replay()
             if b is not None:
-                b.reset()
+                for i in buckets:  # their all-reduce runs beside the next phase's replay
+                    b._launch(i)
+        if self.world > 1:
+            if b is not None:
                 b.finish()
             self.opt.launch()
         self.opt.after_step()

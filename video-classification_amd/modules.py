@@ -86,6 +86,7 @@ class EncoderCNN(_HipModule):
                                    self.compute_dtype, bn=blk[1], groups=T, relu=True)
             else:
                 a = ops.conv_bn(a, blk[0].weight, blk[1], T, blk[0].bias, (1, k, k), (1, 2, 2), 0, relu=True)
+        a = ops.mark_cut(a)  # fc1 below holds four fifths of the model's parameters: its gradient bucket completes here
         # flatten(NCHW) + fc1 == a convolution whose kernel covers the whole feature map
         hf, wf = self.feat_hw
         y = ops.conv(a, self.fc1.weight, self.fc1.bias, (1, hf, wf), 1, 0, relu=True, ci=a.shape[-1])
@@ -168,6 +169,8 @@ def run_resnet_trunk(trunk, x_3d, T, dtype):
     for li in range(4, 8):
         for blk in trunk[li]:
             a = blk.run(a, T)
+        if li < 7:  # stage boundary: the backward pass may be cut here (gradient buckets of the later stages complete)
+            a = ops.mark_cut(a)
     F_, _, H, W, C = a.shape
     return ops.global_avg_pool(a.view(F_, H * W, C))
 

@@ -72,6 +72,19 @@ def _ready(*params):
                 _grad_ready_hook(p)
 
 
+# While a list, every activation a model passes to mark_cut() during forward is appended to it (in forward order).
+_cut_recorder = None
+
+
+def mark_cut(t):
+    """Marks `t` (an activation at a stage boundary of an encoder: everything computed after it depends on it) as a
+    place where the backward pass may be cut into phases.  graph.GraphedTrainStep captures one hipGraph per phase, so
+    that the gradient buckets a phase completed can be all-reduced while the next phase replays.  Returns `t` itself."""
+    if _cut_recorder is not None and t.requires_grad and torch.is_grad_enabled():
+        _cut_recorder.append(t)
+    return t
+
+
 def cast(t, dtype):
     """dtype conversion with the library's cast kernel (float32 <-> bfloat16)."""
     if t.dtype == dtype:

@@ -126,7 +126,9 @@ class SwinT(nn.Module):
         F_, _, H, W, C = y.shape
         x = ops.layer_norm(y.view(F_ * H * W, C), pe.norm).view(F_, H, W, C)
         k = 0
-        for stage in self.layers:
+        for si, stage in enumerate(self.layers):
+            if si > 0:  # stage boundary: the backward pass may be cut here (gradient buckets of the later stages complete)
+                x = ops.mark_cut(x)
             if not isinstance(stage.downsample, nn.Identity):
                 x = stage.downsample.run(x)
             for blk in stage.blocks:

@@ -247,6 +247,7 @@ class GradBucketer:
         self.pending = list(self.sizes)
         self.launched = [False] * len(self.buckets)
         self.handles = []
+        self.late = 0
 
     def notify(self, p):
         b = self.bucket_of.get(id(p))
@@ -278,9 +279,14 @@ class GradBucketer:
     def finish(self):
         """Launch whatever was not signalled, wait for every collective; gradients then hold the SUM over
         ranks (the optimizer folds the 1/world factor into its update)."""
+        # `late` counts the buckets nobody launched during backward (their exchange is not overlapped): zero when every
+        # kernel that writes a parameter gradient reports it; `total_late` accumulates over the run for diagnostics
+        self.late = 0
         for b in range(len(self.buckets)):
             if not self.launched[b]:
+                self.late += 1
                 self._launch(b)
+        self.total_late = getattr(self, "total_late", 0) + self.late
         for h in self.handles:
             h.wait()
         if self.overlap:
