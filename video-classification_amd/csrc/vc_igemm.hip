@@ -142,6 +142,24 @@ __device__ __forceinline__ void glds16(const void* g, bf16* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
+// Bit t of the result = filter tap t (kw fastest, then kh, then kd) of the window whose origin is r lies inside
+// the gather source.  The three axes are tested separately (kd + kh + kw compares) and combined.
+template <int MODE>
+__device__ __forceinline__ unsigned tap_mask(const ConvGeom& g, const RowPos& r) {
+  if (g.kd * g.kh * g.kw == 1)  // 1x1 convolutions and linear layers: one test, no loops
+    return (unsigned)(((unsigned)r.d0 < (unsigned)g.Di) & ((unsigned)r.h0 < (unsigned)g.Hi) & ((unsigned)r.w0 < (unsigned)g.Wi));
+  unsigned dm = 0, hm = 0, wmk = 0;
+  for (int t = 0; t < g.kd; ++t) dm |= (unsigned)((unsigned)(MODE == 0 ? r.d0 + t : r.d0 - t) < (unsigned)g.Di) << t;
+  for (int t = 0; t < g.kh; ++t) hm |= (unsigned)((unsigned)(MODE == 0 ? r.h0 + t : r.h0 - t) < (unsigned)g.Hi) << t;
+  for (int t = 0; t < g.kw; ++t) wmk |= (unsigned)((unsigned)(MODE == 0 ? r.w0 + t : r.w0 - t) < (unsigned)g.Wi) << t;
+  unsigned mk = 0;
+  int sh = 0;
+  for (int a = 0; a < g.kd; ++a)
+    for (int b = 0; b < g.kh; ++b, sh += g.kw)
+      if ((dm >> a) & (hm >> b) & 1u) mk |= wmk << sh;
+  return mk;
+}
+
 // Epilogue shared by the NT kernels: a lane holds 4 consecutive channels of one pixel per 16x16 tile.
 template <int MODE, int WI = 4>
 __device__ __forceinline__ void nt_epilogue(const ConvGeom& g, f32x4 (&acc)[WI][4], int m0, int n0, int wm, int wn,
@@ -675,7 +693,16 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // pipeline runs straight through the tile boundaries, so the first k-tile of the next output tile is already
 // streaming in while the epilogue of the current one is written.  Layers with a short reduction (1x1
 // convolutions with 64..256 channels are 1..4 k-tiles deep) otherwise pay a full memory latency per block.
-template <int MODE, int TN_, int EPI = EPI_NONE>
+//
+// BL = true stages with buffer LDS-DMA loads (buffer_load_dwordx4 ... lds) instead of global ones.  A lane whose
+// offset lies beyond the descriptor's range makes the hardware write ZEROS to its 16 bytes of LDS (measured; the
+// range check looks at the vector offset only, not at the scalar one), so padding taps, rows beyond the matrix
+// and weight rows beyond Co are a sentinel offset: no zero page, no 64-bit pointers, no per-row increments.
+// A staged row is one 32-bit byte offset of its window origin plus a bit mask of the taps that fall inside the
+// source, both computed once per output tile; per filter tap a row costs an add and a select, inside a tap
+// nothing at all (the k-tile's advance is the instruction's scalar offset).  Needs at most 32 filter taps, a
+// stride-1 gather in MODE 1 and operands of less than 4 GiB.
+template <int MODE, int TN_, int EPI = EPI_NONE, bool BL = false>
 __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, const bf16* __restrict__ src,
                                                                    const bf16* __restrict__ wgt,
                                                                    const float* __restrict__ bias,
@@ -776,6 +803,77 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
     }
   };
 
+  // ---- BL staging (see the comment above the kernel) ----
+  constexpr unsigned SENT = 0xFFFFFFF0u;  // beyond every descriptor's range
+  unsigned abase[4], amask[4], avo[4], wvo[NWROW];
+  int t_rd = 0, t_rh = 0, t_rw = 0, s_wk = 0;  // uniform: current tap, byte offset of its weights in a packed row
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16*>(src), 0, (int)((unsigned)(g.N * g.Di * g.Hi * g.Wi) * (unsigned)g.ldi * 2u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16*>(wgt), 0, (int)((unsigned)g.Co * (unsigned)g.ldw * 2u), 0x00020000);
+
+  auto stage_bl = [&](int buf) {
+    const int tile_m = s_tile / tiles_n, tile_n = s_tile - tile_m * tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * TN_;
+    if (s_kt == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const RowPos r = decode_row<MODE>(g, m0 + lrow + 32 * i);  // rows beyond M: coordinates far outside
+        abase[i] = (unsigned)((((r.n * g.Di + r.d0) * g.Hi + r.h0) * g.Wi + r.w0) * g.ldi * 2 + lchunk * 16);
+        amask[i] = tap_mask<MODE>(g, r);
+      }
+#pragma unroll
+      for (int i = 0; i < NWROW; ++i) {
+        const int co = n0 + lrow + 32 * i;
+        wvo[i] = co < g.Co ? (unsigned)(co * g.ldw * 2 + lchunk * 16) : SENT;
+      }
+      tap = 0;
+      cb = 0;
+      t_rd = t_rh = t_rw = 0;
+    }
+    if (cb == 0) {
+      int toff = ((t_rd * g.Hi + t_rh) * g.Wi + t_rw) * g.ldi * 2;
+      if (MODE != 0) toff = -toff;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) avo[i] = ((amask[i] >> tap) & 1u) ? abase[i] + (unsigned)toff : SENT;
+      s_wk = MODE == 2 ? ((t_rd * g.wt_kh + g.wt_h0 + g.wt_hs * t_rh) * g.wt_kw + g.wt_w0 + g.wt_ws * t_rw) * g.Ci * 2
+                       : tap * g.Ci * 2;
+    }
+    bf16* sA = smem + buf * (BM + TN_) * BK;
+    bf16* sW = sA + BM * BK;
+    const int kb = cb * (BK * 2);  // byte advance inside the tap: the instructions' scalar offset
+    // this thread's chunk of a partial last k-tile (single-tap layers whose channel count is no multiple of BK)
+    const bool dead = ktail && cb * BK + lchunk * 8 >= g.Ci;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(sA + (32 * i + 8 * wave) * BK), 16,
+                                               (int)(dead ? SENT : avo[i]), kb, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NWROW; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(sW + (32 * i + 8 * wave) * BK), 16,
+                                               (int)(dead ? SENT : wvo[i]), s_wk + kb, 0, 0);
+    if (++cb == ncb) {
+      cb = 0;
+      ++tap;
+      if (++t_rw == g.kw) {
+        t_rw = 0;
+        if (++t_rh == g.kh) {
+          t_rh = 0;
+          ++t_rd;
+        }
+      }
+    }
+    if (++s_kt == nk) {
+      s_kt = 0;
+      s_tile += G;
+    }
+  };
+#define VC_STAGE_ANY(buf)          \
+  do {                             \
+    if constexpr (BL) stage_bl(buf); \
+    else stage(buf);               \
+  } while (0)
+
   f32x4 acc[WI][4];
 #pragma unroll
   for (int i = 0; i < WI; ++i)
@@ -832,17 +930,17 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
     }
   };
 
-  if (vblock < ntiles) stage(0);
+  if (vblock < ntiles) VC_STAGE_ANY(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   while (c_tile < ntiles) {
-    if (s_tile < ntiles) stage(1);
+    if (s_tile < ntiles) VC_STAGE_ANY(1);
     compute(smem);
     finish_ktile(smem);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (c_tile >= ntiles) break;
-    if (s_tile < ntiles) stage(0);
+    if (s_tile < ntiles) VC_STAGE_ANY(0);
     compute(smem + STAGE);
     finish_ktile(smem + STAGE);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1492,6 +1590,43 @@ bool nt_persist_eligible(const ConvGeom& g, int dtype) {
          (g.Ci % BK == 0 || (single_tap && g.Ci % 8 == 0));
 }
 
+// VC_IGEMM_BL=0 keeps the global-load staging of the persistent kernel everywhere, 2 uses the buffer form for
+// single-tap layers too (A/B measurements); default 1 = buffer form for multi-tap convolutions
+int use_bl() {
+  static const int v = [] {
+    const char* e = getenv("VC_IGEMM_BL");
+    return e ? atoi(e) : 1;
+  }();
+  return v;
+}
+
+// geometries the buffer-load staging covers (see igemm_nt_persist_kernel)
+bool bl_eligible(const ConvGeom& g, int mode) {
+  // Measured on the ResNet-50 layer table: 3x3 layers gain 4-18 % (forward 64 -> 64: 0.267 -> 0.256 ms, its data
+  // gradient 0.301 -> 0.253 ms), single-tap layers lose 0-5 % (their tiles have no per-tap work to save), so those keep
+  // the global-load staging unless VC_IGEMM_BL=2 forces the buffer form (tests, A/B runs).
+  const int taps = g.kd * g.kh * g.kw;
+  if (!use_bl() || taps > 32 || (taps == 1 && use_bl() != 2)) return false;
+  if (mode == 1 && (g.sd != 1 || g.sh != 1 || g.sw != 1)) return false;
+  const int64_t abytes = (int64_t)g.N * g.Di * g.Hi * g.Wi * g.ldi * 2, wbytes = (int64_t)g.Co * g.ldw * 2;
+  return abytes < 0xFFFF0000ll && wbytes < 0xFFFF0000ll;
+}
+
+// launches igemm_nt_persist_kernel<MODE, TN, EPI> with the staging variant the geometry allows
+template <int MODE, int TN, int EPI>
+void launch_persist(const ConvGeom& g, int grid, hipStream_t stream, const void* src, const void* wgt, const float* bias,
+                    void* out, int relu, int out_f32, int beta, int ntiles, float* bn_partial, const void* tail_y,
+                    const uint8_t* tail_bits) {
+  if (bl_eligible(g, MODE))
+    hipLaunchKernelGGL((igemm_nt_persist_kernel<MODE, TN, EPI, true>), dim3(grid), dim3(NTHR), 0, stream, g,
+                       (const bf16*)src, (const bf16*)wgt, bias, out, relu, out_f32, beta, ntiles, bn_partial,
+                       (const bf16*)tail_y, tail_bits);
+  else
+    hipLaunchKernelGGL((igemm_nt_persist_kernel<MODE, TN, EPI, false>), dim3(grid), dim3(NTHR), 0, stream, g,
+                       (const bf16*)src, (const bf16*)wgt, bias, out, relu, out_f32, beta, ntiles, bn_partial,
+                       (const bf16*)tail_y, tail_bits);
+}
+
 template <int MODE>
 int launch_nt(const ConvGeom& g, int dtype, const void* src, const void* wgt, const float* bias, void* out, int relu,
               int out_f32, int beta, hipStream_t stream, const char* who, float* bn_partial = nullptr) {
@@ -1507,12 +1642,12 @@ int launch_nt(const ConvGeom& g, int dtype, const void* src, const void* wgt, co
       if (g.Co <= nt_narrow()) {  // a 128-wide channel tile would be half padding
         const int t64 = ceil_div(g.M, BM) * ceil_div(g.Co, 64);
         const int grid = t64 < nt_persist_blocks() * 3 / 2 ? t64 : nt_persist_blocks() * 3 / 2;
-        hipLaunchKernelGGL((igemm_nt_persist_kernel<MODE, 64>), dim3(grid), dim3(NTHR), 0, stream, g,
-                           (const bf16*)src, (const bf16*)wgt, bias, out, relu, out_f32, beta, t64, bn_partial);
+        launch_persist<MODE, 64, EPI_NONE>(g, grid, stream, src, wgt, bias, out, relu, out_f32, beta, t64, bn_partial,
+                                           nullptr, nullptr);
       } else {
         const int grid = tiles < nt_persist_blocks() ? tiles : nt_persist_blocks();
-        hipLaunchKernelGGL((igemm_nt_persist_kernel<MODE, 128>), dim3(grid), dim3(NTHR), 0, stream, g,
-                           (const bf16*)src, (const bf16*)wgt, bias, out, relu, out_f32, beta, tiles, bn_partial);
+        launch_persist<MODE, 128, EPI_NONE>(g, grid, stream, src, wgt, bias, out, relu, out_f32, beta, tiles, bn_partial,
+                                            nullptr, nullptr);
       }
     } else if (use_glds() && g.Ci % BK == 0 && g.ldi % 8 == 0 && nt_variant() >= 1)
       hipLaunchKernelGGL((igemm_nt_fast_kernel<MODE>), dim3(tiles), dim3(NTHR), 0, stream, g, (const bf16*)src,
@@ -1644,9 +1779,8 @@ int vc_conv_dgrad_bn_tail(const int* desc, int dtype, const void* dy, const void
                  "vc_conv_dgrad_bn_tail: unsupported geometry (ask vc_conv_dgrad_bn_tail_supported)");
   const int tiles = ceil_div(g.M, BM) * ceil_div(g.Co, BN);
   const int grid = tiles < nt_persist_blocks() ? tiles : nt_persist_blocks();
-  hipLaunchKernelGGL((igemm_nt_persist_kernel<1, 128, EPI_BN_TAIL>), dim3(grid), dim3(NTHR), 0, stream, g, (const bf16*)dy,
-                     (const bf16*)w_packed_t, (const float*)nullptr, dx, 0, 0, beta, tiles, bn_partial,
-                     (const bf16*)tail_y, tail_bits);
+  launch_persist<1, 128, EPI_BN_TAIL>(g, grid, stream, dy, w_packed_t, nullptr, dx, 0, 0, beta, tiles, bn_partial, tail_y,
+                                      tail_bits);
   VC_LAUNCH_CHECK("vc_conv_dgrad_bn_tail");
   return VC_OK;
 }
@@ -1670,9 +1804,7 @@ int vc_conv_fwd_residual(const int* desc, int dtype, const void* x, const void* 
                  "vc_conv_fwd_residual: unsupported geometry (ask vc_conv_epilogue_side_supported)");
   const int tiles = ceil_div(g.M, BM) * ceil_div(g.Co, BN);
   const int grid = tiles < nt_persist_blocks() ? tiles : nt_persist_blocks();
-  hipLaunchKernelGGL((igemm_nt_persist_kernel<0, 128, EPI_RESIDUAL>), dim3(grid), dim3(NTHR), 0, stream, g,
-                     (const bf16*)x, (const bf16*)w_packed, bias, y, 0, 0, 0, tiles, (float*)nullptr,
-                     (const bf16*)residual, (const uint8_t*)nullptr);
+  launch_persist<0, 128, EPI_RESIDUAL>(g, grid, stream, x, w_packed, bias, y, 0, 0, 0, tiles, nullptr, residual, nullptr);
   VC_LAUNCH_CHECK("vc_conv_fwd_residual");
   return VC_OK;
 }
@@ -1689,9 +1821,7 @@ int vc_conv_fwd_gelu_dual(const int* desc, int dtype, const void* x, const void*
                  "vc_conv_fwd_gelu_dual: unsupported geometry (ask vc_conv_epilogue_side_supported)");
   const int tiles = ceil_div(g.M, BM) * ceil_div(g.Co, BN);
   const int grid = tiles < nt_persist_blocks() ? tiles : nt_persist_blocks();
-  hipLaunchKernelGGL((igemm_nt_persist_kernel<0, 128, EPI_GELU_DUAL>), dim3(grid), dim3(NTHR), 0, stream, g,
-                     (const bf16*)x, (const bf16*)w_packed, bias, y, 0, 0, 0, tiles, (float*)nullptr,
-                     (const bf16*)y_gelu, (const uint8_t*)nullptr);
+  launch_persist<0, 128, EPI_GELU_DUAL>(g, grid, stream, x, w_packed, bias, y, 0, 0, 0, tiles, nullptr, y_gelu, nullptr);
   VC_LAUNCH_CHECK("vc_conv_fwd_gelu_dual");
   return VC_OK;
 }
@@ -1708,9 +1838,7 @@ int vc_conv_dgrad_gelu(const int* desc, int dtype, const void* dy, const void* w
                  "vc_conv_dgrad_gelu: unsupported geometry (ask vc_conv_epilogue_side_supported)");
   const int tiles = ceil_div(g.M, BM) * ceil_div(g.Co, BN);
   const int grid = tiles < nt_persist_blocks() ? tiles : nt_persist_blocks();
-  hipLaunchKernelGGL((igemm_nt_persist_kernel<1, 128, EPI_GELU_BWD>), dim3(grid), dim3(NTHR), 0, stream, g,
-                     (const bf16*)dy, (const bf16*)w_packed_t, (const float*)nullptr, dx, 0, 0, 0, tiles,
-                     (float*)nullptr, (const bf16*)pre, (const uint8_t*)nullptr);
+  launch_persist<1, 128, EPI_GELU_BWD>(g, grid, stream, dy, w_packed_t, nullptr, dx, 0, 0, 0, tiles, nullptr, pre, nullptr);
   VC_LAUNCH_CHECK("vc_conv_dgrad_gelu");
   return VC_OK;
 }
