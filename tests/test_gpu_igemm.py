@@ -271,3 +271,71 @@ def test_epilogue_side_tensor_forms(cuda):
     # erff on the device against erf in double: a few fp32 ulps before the rounding to bf16
     assert _rel(gl.float().cpu(), want) < 4e-3
     assert (gl.float().cpu() - want.bfloat16().float()).abs().max() <= 2 * want.abs().max() * 2 ** -8
+
+
+BENCH_GEOMETRIES = [
+    # the layer geometries of the bench workload (512 frames of 224 x 224 through ResNet-50; 32 Conv3D clips)
+    # name, N, D, H, W, Ci, Co, k, s, p
+    ("l1_1x1_64_256", 512, 1, 56, 56, 64, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("l1_3x3_64_64", 512, 1, 56, 56, 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("l2_3x3_s2_128_128", 512, 1, 56, 56, 128, 128, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    ("l2_ds_1x1_s2_256_512", 512, 1, 56, 56, 256, 512, (1, 1, 1), (1, 2, 2), (0, 0, 0)),
+    ("l4_3x3_512_512", 512, 1, 7, 7, 512, 512, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("stem_unfolded_7x1_24_64", 512, 1, 224, 112, 24, 64, (1, 7, 1), (1, 2, 1), (0, 3, 0)),
+    ("conv3d_layer2_32_64", 32, 16, 56, 56, 32, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+]
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("case", BENCH_GEOMETRIES, ids=[c[0] for c in BENCH_GEOMETRIES])
+def test_mfma_kernels_at_bench_geometries(cuda, case):
+    """The MFMA kernels at the sizes the benchmark runs them at (1.6 M pixel rows: every workgroup of the persistent
+    kernel walks dozens of tiles in XCD-remapped order, the weight gradient is split over ~1000 workgroups, strided data
+    gradients run as one GEMM per output phase) against the plain-FMA kernels on the same bf16 data, on the device.
+    fp32 accumulation on both sides, different summation order: 2e-4 of the largest magnitude."""
+    from video_classification_amd import _lib as L
+    name, N, D, H, W, Ci, Co, k, s, p = case
+    g = torch.Generator(device="cuda").manual_seed(zlib.crc32(name.encode()) % 1000)
+    desc, (Do, Ho, Wo) = _desc(N, D, H, W, Ci, Co, k, s, p)
+    taps = k[0] * k[1] * k[2]
+    d = L.int_array(desc)
+    dt = torch.bfloat16
+    x = torch.randn(N, D, H, W, Ci, device=cuda, generator=g).to(dt)
+    dy = torch.randn(N, Do, Ho, Wo, Co, device=cuda, generator=g).to(dt)
+    wf = (torch.randn(Co, taps, Ci, device=cuda, generator=g) * 0.1).to(dt)
+    wt = wf.permute(2, 1, 0).contiguous()  # data-gradient pack [Ci][taps][Co]
+    tol = 2e-4
+    # forward (fp32 output), and the bf16 output with the BatchNorm slab sums where the geometry takes that path
+    y = torch.empty(N, Do, Ho, Wo, Co, device=cuda, dtype=torch.float32)
+    yn = torch.empty_like(y)
+    L.call("vc_conv_fwd", d, 1, L.ptr(x), 0, L.ptr(wf), L.ptr(None), L.ptr(y), 0, 0, 1, 0, L.stream())
+    L.call("vc_conv_fwd_naive_bf16", d, 0, L.ptr(x), L.ptr(wf), L.ptr(None), L.ptr(yn), 0, 1, L.stream())
+    torch.cuda.synchronize()
+    assert _rel(y, yn) < tol
+    M = N * Do * Ho * Wo
+    if M % 64 == 0 and L.query("vc_conv_fwd_stats_supported", d, 1, 0, 0) == 1:
+        yb = torch.empty(M, Co, device=cuda, dtype=dt)
+        part = torch.full((M // 64, 2, Co), float("nan"), device=cuda)
+        L.call("vc_conv_fwd_stats", d, 1, L.ptr(x), 0, L.ptr(wf), L.ptr(None), L.ptr(yb), 0, 0, L.ptr(part), L.stream())
+        torch.cuda.synchronize()
+        assert torch.equal(yb, yn.view(M, Co).to(dt)) or _rel(yb.float(), yn.view(M, Co)) < 8e-3  # one bf16 rounding
+        ys = yb.float().view(M // 64, 64, Co)
+        assert _rel(part[:, 0], ys.sum(1)) < 1e-5 and _rel(part[:, 1], (ys * ys).sum(1)) < 1e-5
+        del yb, part, ys
+    del y, yn
+    if "stem" not in name:  # the network's first layer has no data gradient
+        dx = torch.empty(N, D, H, W, Ci, device=cuda, dtype=torch.float32)
+        dxn = torch.full_like(dx, float("nan"))
+        L.call("vc_conv_dgrad", d, 1, L.ptr(dy), 0, L.ptr(wt), L.ptr(dx), 0, 1, 0, L.stream())
+        L.call("vc_conv_fwd_naive_bf16", d, 1, L.ptr(dy), L.ptr(wt), L.ptr(None), L.ptr(dxn), 0, 1, L.stream())
+        torch.cuda.synchronize()
+        assert _rel(dx, dxn) < tol
+        del dx, dxn
+    dw = torch.zeros(Co, taps, Ci, device=cuda, dtype=torch.float32)
+    dwn = torch.zeros_like(dw)
+    db = torch.zeros(Co, device=cuda, dtype=torch.float32)
+    L.call("vc_conv_wgrad", d, 1, L.ptr(x), 0, L.ptr(dy), 0, L.ptr(dw), L.ptr(db), 0, L.stream())
+    L.call("vc_conv_wgrad", d, 1, L.ptr(x), 0, L.ptr(dy), 0, L.ptr(dwn), L.ptr(None), 1, L.stream())
+    torch.cuda.synchronize()
+    assert _rel(dw, dwn) < tol
+    assert _rel(db, dy.float().sum(dim=(0, 1, 2, 3))) < tol
