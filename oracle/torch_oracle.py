@@ -40,6 +40,122 @@ def conv_out(size, k, s, p=0):
     return (size + 2 * p - (k - 1) - 1) // s + 1
 
 
+# --------------------------------------------------------------------------------------
+# bf16 storage emulation (test infrastructure for the bf16 compute path of the HIP kernels)
+# --------------------------------------------------------------------------------------
+# With EMULATE_BF16 set, the restatement below keeps computing in fp32 but rounds to bfloat16 wherever the HIP path
+# STORES a tensor in bf16: the clip, the packed weights, every convolution / linear / normalisation / pooling /
+# attention output, the LSTM's h_t, and -- through the backward of the same rounding nodes -- the activation
+# gradients at the same places (gate gradients of the LSTM included).  Accumulation, statistics, the LSTM cell
+# state, logits and loss stay fp32, as on the device.  Off (the default), every helper is the identity and the
+# oracle is the fp32 restatement the golden vectors pin.  The emulation is approximate where the device rounds a
+# sum in two steps (gradients accumulated into a bf16 buffer by two kernels, a residual added to an already
+# rounded GEMM result): there it rounds once.
+EMULATE_BF16 = False
+
+
+def _bf(x):
+    return x.bfloat16().float()
+
+
+class _Round(torch.autograd.Function):
+    """value stored in bf16, and its gradient stored in bf16"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return _bf(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _bf(g)
+
+
+class _RoundValue(torch.autograd.Function):
+    """bf16 copy of an fp32 master tensor (packed weights): the gradient stays fp32"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return _bf(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _RoundGrad(torch.autograd.Function):
+    """fp32 value whose gradient is stored in bf16 (LSTM gate pre-activations)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _bf(g)
+
+
+def _r(x):
+    return _Round.apply(x) if EMULATE_BF16 else x
+
+
+def _w(w):
+    return _RoundValue.apply(w) if (EMULATE_BF16 and w is not None) else w
+
+
+def _rg(x):
+    return _RoundGrad.apply(x) if EMULATE_BF16 else x
+
+
+def _conv(m, x):
+    """m(x) for an nn.Conv2d / nn.Conv3d, output stored in the compute type"""
+    if not EMULATE_BF16:
+        return m(x)
+    f = F.conv3d if isinstance(m, nn.Conv3d) else F.conv2d
+    return _r(f(x, _w(m.weight), m.bias, m.stride, m.padding))
+
+
+def _lin(m, x, f32_out=False, relu=False):
+    """m(x) for an nn.Linear (optionally followed by ReLU); f32_out: the device writes this output in fp32"""
+    if not EMULATE_BF16:
+        y = m(x)
+        return F.relu(y) if relu else y
+    y = F.linear(x, _w(m.weight), m.bias)
+    if relu:
+        y = F.relu(y)
+    return y if f32_out else _r(y)
+
+
+def _lstm(m, x):
+    """nn.LSTM(batch_first) with zero initial state.  Emulation: the recurrence written out, with h_t stored in bf16
+    (it is what the next step, the next layer and the output read), gate pre-activations and the cell state in fp32,
+    gate gradients stored in bf16."""
+    if not EMULATE_BF16:
+        return m(x, None)[0]
+    B, T, _ = x.shape
+    H = m.hidden_size
+    inp = _r(x)
+    for l in range(m.num_layers):
+        outs = []
+        for d in range(2 if m.bidirectional else 1):
+            sfx = f"_l{l}" + ("_reverse" if d else "")
+            w_ih, w_hh = _w(getattr(m, "weight_ih" + sfx)), _w(getattr(m, "weight_hh" + sfx))
+            bias = getattr(m, "bias_ih" + sfx) + getattr(m, "bias_hh" + sfx)
+            gx = F.linear(inp, w_ih, bias)                       # [B,T,4H] fp32 on the device too
+            h = x.new_zeros(B, H)
+            c = x.new_zeros(B, H)
+            hs = [None] * T
+            for t in (range(T - 1, -1, -1) if d else range(T)):
+                gates = _rg(gx[:, t] + F.linear(h, w_hh))
+                i, f, g, o = gates.chunk(4, dim=1)
+                c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+                h = _r(torch.sigmoid(o) * torch.tanh(c))
+                hs[t] = h
+            outs.append(torch.stack(hs, dim=1))
+        inp = torch.cat(outs, dim=-1) if len(outs) > 1 else outs[0]
+        # inter-layer dropout is only ever exercised at p = 0 / eval in the parity tests
+    return inp
+
+
 def _per_frame(fn, clip):
     """Apply fn to every time step of [B,T,...] and restack as [B,T,E].
 
@@ -73,9 +189,12 @@ class EncoderCNN(nn.Module):
         self.fc3 = nn.Linear(fc_hidden2, CNN_embed_dim)
 
     def _frame(self, x):
-        x = self.conv4(self.conv3(self.conv2(self.conv1(x)))).flatten(1)
-        x = F.relu(self.fc2(F.relu(self.fc1(x))))
-        return self.fc3(F.dropout(x, p=self.drop_p, training=self.training))
+        x = _r(x)
+        for blk in (self.conv1, self.conv2, self.conv3, self.conv4):  # Conv2d, BatchNorm2d, ReLU
+            x = _r(blk[2](blk[1](_conv(blk[0], x))))
+        x = x.flatten(1)
+        x = _lin(self.fc2, _lin(self.fc1, x, relu=True), relu=True)
+        return _lin(self.fc3, F.dropout(x, p=self.drop_p, training=self.training), f32_out=True)
 
     def forward(self, x_3d):
         return _per_frame(self._frame, x_3d)
@@ -99,11 +218,11 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        idt = x if self.downsample is None else self.downsample(x)
-        y = self.relu(self.bn1(self.conv1(x)))
-        y = self.relu(self.bn2(self.conv2(y)))
-        y = self.bn3(self.conv3(y))
-        return self.relu(y + idt)
+        idt = x if self.downsample is None else _r(self.downsample[1](_conv(self.downsample[0], x)))
+        y = _r(self.relu(self.bn1(_conv(self.conv1, x))))
+        y = _r(self.relu(self.bn2(_conv(self.conv2, y))))
+        y = self.bn3(_conv(self.conv3, y))
+        return _r(self.relu(y + idt))
 
 
 RESNET_LAYERS = {"resnet50": (3, 4, 6, 3), "resnet101": (3, 4, 23, 3), "resnet152": (3, 8, 36, 3)}
@@ -144,12 +263,12 @@ class _HeadBN(nn.Module):
     Swin encoders; `drop_after_first` distinguishes model_components.py:294-304 from :180-185."""
 
     def _head(self, x, drop_after_first):
-        x = F.relu(self.bn1(self.fc1(x)))
+        x = _r(F.relu(self.bn1(_lin(self.fc1, x))))
         if drop_after_first:
             x = F.dropout(x, p=self.drop_p, training=self.training)
-        x = F.relu(self.bn2(self.fc2(x)))
+        x = _r(F.relu(self.bn2(_lin(self.fc2, x))))
         x = F.dropout(x, p=self.drop_p, training=self.training)
-        return self.fc3(x)
+        return _lin(self.fc3, x, f32_out=True)
 
     def _make_head(self, feat, h1, h2, embed):
         self.fc1 = nn.Linear(feat, h1)
@@ -169,8 +288,17 @@ class ResCNNEncoder(_HeadBN):
         self.resnet = make_resnet_trunk(arch, width)
         self._make_head(32 * width, fc_hidden1, fc_hidden2, CNN_embed_dim)
 
+    def _trunk(self, f):
+        if not EMULATE_BF16:
+            return self.resnet(f)
+        t = self.resnet
+        a = _r(t[3](t[2](t[1](_conv(t[0], _r(f))))))  # conv1, bn1, relu, maxpool: one stored tensor
+        for li in range(4, 8):
+            a = t[li](a)
+        return _r(t[8](a))
+
     def forward(self, x_3d):
-        return _per_frame(lambda f: self._head(self.resnet(f).flatten(1), False), x_3d)
+        return _per_frame(lambda f: self._head(self._trunk(f).flatten(1), False), x_3d)
 
 
 # --------------------------------------------------------------------------------------
@@ -185,9 +313,9 @@ class DecoderRNN(nn.Module):
         self.fc2 = nn.Linear(h_FC_dim, num_classes)
 
     def forward(self, x_RNN):
-        seq, _ = self.LSTM(x_RNN, None)  # zero initial state
-        x = F.relu(self.fc1(seq[:, -1, :]))
-        return self.fc2(F.dropout(x, p=self.drop_p, training=self.training))
+        seq = _lstm(self.LSTM, x_RNN)  # zero initial state
+        x = _lin(self.fc1, seq[:, -1, :], relu=True)
+        return _lin(self.fc2, F.dropout(x, p=self.drop_p, training=self.training), f32_out=True)
 
 
 # --------------------------------------------------------------------------------------
@@ -228,7 +356,7 @@ class WindowAttention(nn.Module):
 
     def forward(self, x, mask):  # x: [nWin_total, N, C]
         Bw, N, C = x.shape
-        qkv = self.qkv(x).reshape(Bw, N, 3, self.heads, C // self.heads).permute(2, 0, 3, 1, 4)
+        qkv = _lin(self.qkv, x).reshape(Bw, N, 3, self.heads, C // self.heads).permute(2, 0, 3, 1, 4)
         q, k, v = qkv[0] * self.scale, qkv[1], qkv[2]
         attn = q @ k.transpose(-2, -1)
         bias = self.relative_position_bias_table[self.relative_position_index.view(-1)].view(N, N, -1)
@@ -236,8 +364,9 @@ class WindowAttention(nn.Module):
         if mask is not None:
             nW = mask.shape[0]
             attn = (attn.view(Bw // nW, nW, self.heads, N, N) + mask[None, :, None]).view(Bw, self.heads, N, N)
-        attn = attn.softmax(dim=-1)
-        return self.proj((attn @ v).transpose(1, 2).reshape(Bw, N, C))
+        attn = _r(attn.softmax(dim=-1))  # the probabilities enter the P.V product in the compute type
+        # the projection's result joins the residual stream in the caller (one stored tensor: x + proj)
+        return F.linear(_r((attn @ v).transpose(1, 2).reshape(Bw, N, C)), _w(self.proj.weight), self.proj.bias)
 
 
 class SwinMlp(nn.Module):
@@ -247,7 +376,7 @@ class SwinMlp(nn.Module):
         self.fc2 = nn.Linear(4 * dim, dim)
 
     def forward(self, x):
-        return self.fc2(F.gelu(self.fc1(x)))
+        return F.linear(_r(F.gelu(_lin(self.fc1, x))), _w(self.fc2.weight), self.fc2.bias)
 
 
 class SwinBlock(nn.Module):
@@ -265,7 +394,7 @@ class SwinBlock(nn.Module):
     def forward(self, x):  # x: [B, H, W, C]; drop-path is stochastic and therefore 0 in the oracle
         B, H, W, C = x.shape
         ws = self.ws
-        y = self.norm1(x)
+        y = _r(self.norm1(x))
         if self.shift:
             y = torch.roll(y, (-self.shift, -self.shift), (1, 2))
         y = y.view(B, H // ws, ws, W // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, C)
@@ -273,8 +402,8 @@ class SwinBlock(nn.Module):
         y = y.view(B, H // ws, W // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, C)
         if self.shift:
             y = torch.roll(y, (self.shift, self.shift), (1, 2))
-        x = x + y
-        return x + self.mlp(self.norm2(x))
+        x = _r(x + y)
+        return _r(x + self.mlp(_r(self.norm2(x))))
 
 
 class PatchMerging(nn.Module):
@@ -286,7 +415,7 @@ class PatchMerging(nn.Module):
     def forward(self, x):  # [B,H,W,C] -> [B,H/2,W/2,2C]
         B, H, W, C = x.shape
         x = x.reshape(B, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 4, 2, 5).flatten(3)
-        return self.reduction(self.norm(x))
+        return _lin(self.reduction, _r(self.norm(x)))
 
 
 class SwinStage(nn.Module):
@@ -307,7 +436,7 @@ class PatchEmbed(nn.Module):
         self.norm = nn.LayerNorm(dim)
 
     def forward(self, x):
-        return self.norm(self.proj(x).permute(0, 2, 3, 1))
+        return _r(self.norm(_conv(self.proj, _r(x)).permute(0, 2, 3, 1)))
 
 
 class SwinT(nn.Module):
@@ -329,7 +458,7 @@ class SwinT(nn.Module):
 
     def forward(self, x):
         x = self.layers(self.patch_embed(x))
-        return self.norm(x).mean(dim=(1, 2))
+        return _r(_r(self.norm(x)).mean(dim=(1, 2)))
 
 
 class SwinTransformerEncoder(_HeadBN):
@@ -352,7 +481,7 @@ class ClusterSwinEncoder(nn.Module):
         self.proj = nn.Linear(self.backbone.num_features, embed_dim)
 
     def forward(self, x):
-        g = _per_frame(lambda f: self.proj(self.backbone(f)), x)            # [B,T,E]
+        g = _per_frame(lambda f: _lin(self.proj, self.backbone(f), f32_out=True), x)  # [B,T,E]
         c = g.unsqueeze(2).repeat(1, 1, self.k_tokens, 1)                   # model_components.py:468
         return g, c
 
@@ -371,8 +500,8 @@ class TCG_LSTM(nn.Module):
                                 nn.Linear(256, num_classes))
 
     def forward(self, g, c):
-        h_s, _ = self.lstm_short(torch.cat([g, c.mean(2)], dim=-1))          # [B,T,2H]
-        h_l, _ = self.lstm_long(g[:, ::self.down, :])                        # [B,T/down,H]
+        h_s = _lstm(self.lstm_short, torch.cat([g, c.mean(2)], dim=-1))      # [B,T,2H]
+        h_l = _lstm(self.lstm_long, g[:, ::self.down, :])                    # [B,T/down,H]
         up = F.interpolate(h_l.transpose(1, 2), size=h_s.size(1), mode="linear", align_corners=False).transpose(1, 2)
         up2 = torch.cat([up, up], dim=-1)
         gate = self.gate(torch.cat([h_s, up2], dim=-1))
@@ -399,7 +528,15 @@ class Conv3DModel(nn.Module):
                                 nn.Dropout(config.dropout_p), nn.Linear(512, config.num_classes))
 
     def forward(self, x):
-        return self.fc(self.conv3d(x).flatten(1))
+        if not EMULATE_BF16:
+            return self.fc(self.conv3d(x).flatten(1))
+        a = _r(x)
+        for i in range(4):  # Conv3d, BatchNorm3d, ReLU, MaxPool3d: the pooled tensor is what the device stores
+            cv, bn, act, pool = self.conv3d[4 * i:4 * i + 4]
+            a = _r(pool(act(bn(_conv(cv, a)))))
+        f = _r(self.conv3d[16](a).flatten(1))
+        f = _lin(self.fc[1], self.fc[0](f), relu=True)
+        return _lin(self.fc[4], self.fc[3](f), f32_out=True)
 
 
 # --------------------------------------------------------------------------------------

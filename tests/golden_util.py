@@ -102,3 +102,22 @@ def check_grads(named_params, grefs, tol, cancelled=()):
         assert l2_rel(g, gref) < tol, (k, "l2", l2_rel(g, gref))
         if tol <= 1e-2:  # the max-norm only means something on the exact (fp32) path
             assert max_rel(g, gref) < 3 * tol, (k, "max", max_rel(g, gref))
+
+
+def report_against_noise_floor(title, err, floor):
+    w, f = max(err, key=err.get), max(floor, key=floor.get)
+    med = lambda d: sorted(d.values())[len(d) // 2]  # noqa: E731
+    print(f"\n[{title}] worst {w} {err[w]:.3e} (run-to-run worst {f} {floor[f]:.3e}), median {med(err):.3e} "
+          f"(run-to-run {med(floor):.3e})")
+
+
+def assert_within_noise_floor(err, floor, factor=2.0, slack=5e-3, at_least=0.0):
+    """err[k]: relative L2 distance of tensor k to the bf16-emulating oracle; floor[k]: distance between two runs of the
+    HIP path on identical inputs (its own noise floor: fp32 atomics arrive in a different order, and bf16 rounding
+    amplifies any difference up to the rounding noise).  The oracle may be further from a run than the run's repetition
+    by `factor` (worst tensor and median over tensors) plus `slack`.  `at_least`: bound for paths that repeat
+    (nearly) bit for bit, where the floor says nothing and the distance is the emulation's own infidelity."""
+    med = lambda d: sorted(d.values())[len(d) // 2]  # noqa: E731
+    assert max(err.values()) <= max(factor * max(floor.values()) + slack, at_least), (
+        max(err, key=err.get), max(err.values()), max(floor.values()))
+    assert med(err) <= max(factor * med(floor) + slack, at_least), (med(err), med(floor))

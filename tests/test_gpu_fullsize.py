@@ -67,8 +67,45 @@ def _compare(mine, out_m, loss_m, ref_out, ref_loss, ref_grads, dt, tol_g, cance
                 assert p.grad.abs().max().item() <= tol_g * ref_grads[wk].abs().max().item(), k
 
 
+def _emulating(O, on):
+    """Context: the oracle rounds to bf16 wherever the HIP path stores bf16 (oracle/torch_oracle.py, EMULATE_BF16)."""
+    import contextlib
+
+    @contextlib.contextmanager
+    def cm():
+        old, O.EMULATE_BF16 = O.EMULATE_BF16, on
+        try:
+            yield
+        finally:
+            O.EMULATE_BF16 = old
+    return cm()
+
+
+def _vs_emulation(mine, out, emu, rerun, cancelled=(), at_least=0.0):
+    """The bf16 HIP path against the oracle run with bf16 storage emulation, bounded by the path's own run-to-run
+    noise floor (`rerun()` repeats forward + backward on the same model and inputs and returns the output): see
+    tests/test_gpu_models.py::test_resnet_blocks_bf16_against_emulating_oracle for why no tighter bound exists for a
+    deep bf16 network, and for the tight single-block bound.  The Swin models repeat bit for bit up to their fp32 weight
+    gradient atomics (LayerNorm has no cross-row sums), so their floor is ~1e-6 and `at_least` states the bound: what
+    separates the device from the emulation there is the emulation's own infidelity (rounding inside the attention
+    kernel, sums rounded in two steps), amplified by whatever follows it."""
+    emu_out, emu_grads = emu
+    keep = lambda k: not any(k.endswith(c) for c in cancelled)  # noqa: E731
+    g1 = {k: p.grad.detach().cpu().clone() for k, p in mine.named_parameters() if keep(k)}
+    o1 = out.detach().float().cpu()
+    for p in mine.parameters():
+        p.grad = None
+    o2 = rerun().detach().float().cpu()
+    g2 = {k: p.grad.detach().cpu() for k, p in mine.named_parameters() if keep(k)}
+    err = {k: G.l2_rel(g1[k], emu_grads[k]) for k in g1}
+    floor = {k: G.l2_rel(g2[k], g1[k]) for k in g1}
+    err["logits"], floor["logits"] = G.l2_rel(o1, emu_out), G.l2_rel(o2, o1)
+    G.report_against_noise_floor("bf16 vs bf16-emulating oracle", err, floor)
+    G.assert_within_noise_floor(err, floor, at_least=at_least)
+
+
 @functools.lru_cache(maxsize=None)
-def _resnet_ref():
+def _resnet_ref(emulate=False):
     from oracle import torch_oracle as O
     cfg = types.SimpleNamespace(CNN_fc_hidden1=1024, CNN_fc_hidden2=768, CNN_embed_dim=512, dropout_p=0.0,
                                 use_pretrained=False, RNN_hidden_layers=2, RNN_hidden_nodes=512, RNN_FC_dim=256,
@@ -87,9 +124,10 @@ def _resnet_ref():
          0.3 * torch.randn(B * 16, 3, 224, 224, generator=g)).view(B, 16, 3, 224, 224)
     y = torch.randint(0, 101, (B, 1), generator=g)
     ref.train()
-    out = ref(x)
-    loss = nn.CrossEntropyLoss()(out, y.squeeze(1))
-    loss.backward()
+    with _emulating(O, emulate):
+        out = ref(x)
+        loss = nn.CrossEntropyLoss()(out, y.squeeze(1))
+        loss.backward()
     return cfg, ref.state_dict(), x, y, out.detach(), loss.item(), {k: p.grad for k, p in ref.named_parameters()}
 
 
@@ -120,10 +158,19 @@ def test_resnet50_crnn_ucf_shape(cuda, dt):
              cancelled=["encoder.fc1.bias", "encoder.fc2.bias"],
              group_tol={"decoder.": 1e-4, "encoder.fc": 1e-4, "encoder.bn": 1e-4} if f32 else
              {"decoder.fc2": 3e-2, "decoder.": 0.12})
+    if not f32:
+        e = _resnet_ref(True)
+
+        def rerun():
+            o = mine(x.to(cuda))
+            ops.cross_entropy(o, y.to(cuda)).backward()
+            torch.cuda.synchronize()
+            return o
+        _vs_emulation(mine, out, (e[4], e[6]), rerun, cancelled=["encoder.fc1.bias", "encoder.fc2.bias"])
 
 
 @functools.lru_cache(maxsize=None)
-def _swin_ref():
+def _swin_ref(emulate=False):
     from oracle import torch_oracle as O
     torch.manual_seed(12)
     ref = O.SwinTCGModel(O.ClusterSwinEncoder(embed_dim=96, k_tokens=8), O.TCG_LSTM(96, 512, 2, 8, 4, 101, 0.0))
@@ -131,9 +178,10 @@ def _swin_ref():
     x = torch.randn(4, 16, 3, 224, 224, generator=g)
     y = torch.randint(0, 101, (4, 1), generator=g)
     ref.train()
-    out = ref(x)
-    loss = nn.CrossEntropyLoss()(out, y.squeeze(1))
-    loss.backward()
+    with _emulating(O, emulate):
+        out = ref(x)
+        loss = nn.CrossEntropyLoss()(out, y.squeeze(1))
+        loss.backward()
     return ref.state_dict(), x, y, out.detach(), loss.item(), {k: p.grad for k, p in ref.named_parameters()}
 
 
@@ -157,10 +205,19 @@ def test_cluster_swin_tcg_ucf_shape(cuda, dt):
     ops.check_lstm_error()
     # measured: fp32 worst 8e-6 (patch embedding); bf16 worst 1.5e-2 (a stage-4 bias table), decoder 7e-3
     _compare(mine, out, loss.item(), ref_out, ref_loss, ref_grads, dt, 1e-4 if dt == torch.float32 else 5e-2)
+    if dt == torch.bfloat16:
+        e = _swin_ref(True)
+
+        def rerun():
+            o = mine(x.to(cuda))
+            ops.cross_entropy(o, y.to(cuda)).backward()
+            torch.cuda.synchronize()
+            return o
+        _vs_emulation(mine, out, (e[3], e[5]), rerun, at_least=5e-2)  # measured 1.5e-2
 
 
 @functools.lru_cache(maxsize=None)
-def _swin_rnn_ref():
+def _swin_rnn_ref(emulate=False):
     from oracle import torch_oracle as O
     torch.manual_seed(14)
     # what the reference's factory builds for --model swintransformer-RNN (train.py:256-278 with the Config defaults
@@ -171,9 +228,10 @@ def _swin_rnn_ref():
     x = torch.randn(B, 16, 3, 224, 224, generator=g)
     y = torch.randint(0, 101, (B, 1), generator=g)
     ref.train()
-    out = ref(x)
-    loss = nn.CrossEntropyLoss()(out, y.squeeze(1))
-    loss.backward()
+    with _emulating(O, emulate):
+        out = ref(x)
+        loss = nn.CrossEntropyLoss()(out, y.squeeze(1))
+        loss.backward()
     bufs = {k: v.clone() for k, v in ref.named_buffers()}
     return ref.state_dict(), x, y, out.detach(), loss.item(), {k: p.grad for k, p in ref.named_parameters()}, bufs
 
@@ -215,10 +273,22 @@ def test_swin_rnn_ucf_shape(cuda, dt):
             assert int(mb[k]) == int(v) == 16, k   # one update per time step
         elif "running_" in k:
             assert G.max_rel(mb[k].cpu(), v) < (1e-4 if f32 else 2e-2), k
+    if not f32:   # after the buffers: the second pass below updates the running statistics again
+        e = _swin_rnn_ref(True)
+
+        def rerun():
+            o = mine(x.to(cuda))
+            ops.cross_entropy(o, y.to(cuda)).backward()
+            torch.cuda.synchronize()
+            return o
+        # BatchNorm1d over 6 samples amplifies the emulation's ~1e-3 infidelity as it amplifies bf16 rounding itself
+        # (fp32: 1e-7 -> 1.2e-4 in this model): no tighter than the bound against the fp32 oracle (measured 0.63)
+        _vs_emulation(mine, out, (e[3], e[5]), rerun, at_least=0.9,
+                      cancelled=["encoder.fc1.bias", "encoder.fc2.bias", "encoder.swin.norm.bias"])
 
 
 @functools.lru_cache(maxsize=None)
-def _conv3d_ref():
+def _conv3d_ref(emulate=False):
     from oracle import torch_oracle as O
     torch.manual_seed(13)
     ref = O.Conv3DModel(G.conv3d_config())
@@ -226,9 +296,10 @@ def _conv3d_ref():
     x = torch.randn(4, 1, 16, 112, 112, generator=g)
     y = torch.randint(0, 101, (4, 1), generator=g)
     ref.train()
-    out = ref(x)
-    loss = nn.CrossEntropyLoss()(out, y.squeeze(1))
-    loss.backward()
+    with _emulating(O, emulate):
+        out = ref(x)
+        loss = nn.CrossEntropyLoss()(out, y.squeeze(1))
+        loss.backward()
     return ref.state_dict(), x, y, out.detach(), loss.item(), {k: p.grad for k, p in ref.named_parameters()}
 
 
@@ -253,3 +324,12 @@ def test_conv3d_native_shape(cuda, dt):
     _compare(mine, out, loss.item(), ref_out, ref_loss, ref_grads, dt, 1e-2 if f32 else 0.5,
              cancelled=[f"conv3d.{i}.bias" for i in (0, 4, 8, 12)],
              group_tol={"fc.": 1e-5} if f32 else {"fc.4": 2e-2, "fc.": 0.12})
+    if not f32:
+        e = _conv3d_ref(True)
+
+        def rerun():
+            o = mine(x.to(cuda))
+            ops.cross_entropy(o, y.to(cuda)).backward()
+            torch.cuda.synchronize()
+            return o
+        _vs_emulation(mine, out, (e[3], e[5]), rerun, cancelled=[f"conv3d.{i}.bias" for i in (0, 4, 8, 12)])
