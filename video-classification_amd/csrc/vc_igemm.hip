@@ -525,7 +525,7 @@ __device__ __forceinline__ float gelu_grad_dev(float x) {  // d/dx [x * Phi(x)] 
   return cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
 
-template <int MODE, int WI, int EPI = EPI_NONE>
+template <int MODE, int WI, int EPI = EPI_NONE, bool HAS_BIAS = true>
 __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[WI][4], int m0, int n0, int wm,
                                                 int wn, int lane, const float* __restrict__ bias,
                                                 bf16* __restrict__ out, int relu, int beta, bf16* stage_buf,
@@ -539,7 +539,7 @@ __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[
   for (int i = 0; i < WI; ++i) {
     const int col = i * 16 + q * 4;  // channel inside the wave's WC
     float b[4] = {0.f, 0.f, 0.f, 0.f};
-    if (bias) {
+    if (HAS_BIAS && bias) {
       const int co = n0 + wn * WC + col;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
@@ -702,7 +702,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // source, both computed once per output tile; per filter tap a row costs an add and a select, inside a tap
 // nothing at all (the k-tile's advance is the instruction's scalar offset).  Needs at most 32 filter taps, a
 // stride-1 gather in MODE 1 and operands of less than 4 GiB.
-template <int MODE, int TN_, int EPI = EPI_NONE, bool BL = false>
+template <int MODE, int TN_, int EPI = EPI_NONE, bool BL = false, int NA = 3>
 __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, const bf16* __restrict__ src,
                                                                    const bf16* __restrict__ wgt,
                                                                    const float* __restrict__ bias,
@@ -711,8 +711,13 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
                                                                    float* __restrict__ bn_partial,
                                                                    const bf16* __restrict__ tail_y = nullptr,
                                                                    const uint8_t* __restrict__ tail_bits = nullptr) {
-  constexpr int STAGE = (BM + TN_) * BK;
-  __shared__ __attribute__((aligned(1024))) bf16 smem[2 * STAGE];
+  // NA staged k-tiles of the source rows and two of the weight rows.  NA = 3 keeps one source k-tile in flight ACROSS
+  // the barrier (a counted vmcnt leaves its loads outstanding): the source streams from HBM, whose latency under load
+  // is several times one k-tile of products; the weights come out of L2 and get by with one k-tile of lead.
+  constexpr int ASZ = BM * BK, WSZ = TN_ * BK;  // elements per staged k-tile
+  __shared__ __attribute__((aligned(1024))) bf16 smem[NA * ASZ + 2 * WSZ];
+  bf16* const sA0 = smem;
+  bf16* const sW0 = smem + NA * ASZ;
   constexpr int WI = TN_ / 32;   // 16-channel tiles per wave
   constexpr int NWROW = TN_ / 32;  // weight rows staged per thread
 
@@ -727,25 +732,68 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
   const int lrow = tid >> 3, pchunk = tid & 7;
   const int lchunk = pchunk ^ ((lrow >> 1) & 7);
   // k-tiles per tap; a single-tap layer (linear, 1x1 convolution) may have any channel count that is a
-  // multiple of 8: the chunks of its last k-tile that lie beyond Ci read the zero page
+  // multiple of 8: the chunks of its last k-tile that lie beyond Ci read zeros
   const int ncb = (g.Ci + BK - 1) / BK;
   const int nk = g.kd * g.kh * g.kw * ncb;  // k-tiles per output tile (>= 1)
   const bool ktail = (g.Ci % BK) != 0;
   const bf16* zero = reinterpret_cast<const bf16*>(vc_zero_src);
 
-  // staging state (runs one k-tile ahead of the multiply)
-  int s_tile = vblock, s_kt = 0, tap = 0, cb = 0;
+  // A staging cursor: which k-tile of which output tile comes next.  The source rows and the weight rows have one
+  // each (the source runs further ahead); both are wave-uniform.
+  struct KCursor {
+    int tile, kt, tap, cb, rd, rh, rw;
+  };
+  auto advance = [&](KCursor& c) {
+    if (++c.cb == ncb) {
+      c.cb = 0;
+      ++c.tap;
+      if (++c.rw == g.kw) {
+        c.rw = 0;
+        if (++c.rh == g.kh) {
+          c.rh = 0;
+          ++c.rd;
+        }
+      }
+    }
+    if (++c.kt == nk) {
+      c.kt = 0;
+      c.tap = c.cb = c.rd = c.rh = c.rw = 0;
+      c.tile += G;
+    }
+  };
+  KCursor ca{vblock, 0, 0, 0, 0, 0, 0}, cw = ca;
+
+  // ---- staging by global LDS-DMA loads ----
   RowPos rp[4];
   const bf16* ap[4];
   const bf16* wp[4];
   int ainc[4], winc[4];
 
-  auto stage = [&](int buf) {
-    const int tile_m = s_tile / tiles_n, tile_n = s_tile - tile_m * tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * TN_;
-    if (s_kt == 0) {  // first k-tile of an output tile: its rows and weight rows
+  auto stage_a_gl = [&](bf16* sA, KCursor& c) {
+    if (c.kt == 0) {  // first k-tile of an output tile: its rows
+      const int m0 = (c.tile / tiles_n) * BM;
 #pragma unroll
       for (int i = 0; i < 4; ++i) rp[i] = decode_row<MODE>(g, m0 + lrow + 32 * i);
+    }
+    if (c.cb == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int pix = gather_pixel<MODE>(g, rp[i], c.rd, c.rh, c.rw);
+        const bool ok = pix >= 0;
+        ap[i] = ok ? src + (size_t)pix * g.ldi + lchunk * 8 : zero;
+        ainc[i] = ok ? BK : 0;
+      }
+    }
+    const bool dead = ktail && c.cb * BK + lchunk * 8 >= g.Ci;  // this thread's chunk of a partial last k-tile
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(dead ? zero : ap[i], sA + (32 * i + 8 * wave) * BK);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ap[i] += ainc[i];
+    advance(c);
+  };
+  auto stage_w_gl = [&](bf16* sW, KCursor& c) {
+    const int tile_m = c.tile / tiles_n, n0 = (c.tile - tile_m * tiles_n) * TN_;
+    if (c.kt == 0) {
 #pragma unroll
       for (int i = 0; i < NWROW; ++i) {
         const int co = n0 + lrow + 32 * i;
@@ -753,125 +801,85 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
         wp[i] = ok ? wgt + (size_t)co * g.ldw + lchunk * 8 : zero;
         winc[i] = ok ? BK : 0;
       }
-      tap = 0;
-      cb = 0;
     }
-    if (cb == 0) {
-      int t2, rd, rh, rw;
-      fd_divmod(tap, g.fkw, t2, rw);
-      fd_divmod(t2, g.fkh, rd, rh);
+    if (MODE == 2 && c.cb == 0) {
+      const int wcol = ((c.rd * g.wt_kh + g.wt_h0 + g.wt_hs * c.rh) * g.wt_kw + g.wt_w0 + g.wt_ws * c.rw) * g.Ci;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int pix = gather_pixel<MODE>(g, rp[i], rd, rh, rw);
-        const bool ok = pix >= 0;
-        ap[i] = ok ? src + (size_t)pix * g.ldi + lchunk * 8 : zero;
-        ainc[i] = ok ? BK : 0;
-      }
-      if (MODE == 2) {
-        const int wcol = ((rd * g.wt_kh + g.wt_h0 + g.wt_hs * rh) * g.wt_kw + g.wt_w0 + g.wt_ws * rw) * g.Ci;
-#pragma unroll
-        for (int i = 0; i < NWROW; ++i) {
-          const int co = n0 + lrow + 32 * i;
-          if (co < g.Co) wp[i] = wgt + (size_t)co * g.ldw + wcol + lchunk * 8;
-        }
+      for (int i = 0; i < NWROW; ++i) {
+        const int co = n0 + lrow + 32 * i;
+        if (co < g.Co) wp[i] = wgt + (size_t)co * g.ldw + wcol + lchunk * 8;
       }
     }
-    bf16* sA = smem + buf * (BM + TN_) * BK;
-    bf16* sW = sA + BM * BK;
-    if (ktail && cb * BK + lchunk * 8 >= g.Ci) {  // this thread's chunk of a partial last k-tile
+    const bool dead = ktail && c.cb * BK + lchunk * 8 >= g.Ci;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) glds16(zero, sA + (32 * i + 8 * wave) * BK);
-#pragma unroll
-      for (int i = 0; i < NWROW; ++i) glds16(zero, sW + (32 * i + 8 * wave) * BK);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) glds16(ap[i], sA + (32 * i + 8 * wave) * BK);
-#pragma unroll
-      for (int i = 0; i < NWROW; ++i) glds16(wp[i], sW + (32 * i + 8 * wave) * BK);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) ap[i] += ainc[i];
+    for (int i = 0; i < NWROW; ++i) glds16(dead ? zero : wp[i], sW + (32 * i + 8 * wave) * BK);
 #pragma unroll
     for (int i = 0; i < NWROW; ++i) wp[i] += winc[i];
-    if (++cb == ncb) {
-      cb = 0;
-      ++tap;
-    }
-    if (++s_kt == nk) {
-      s_kt = 0;
-      s_tile += G;
-    }
+    advance(c);
   };
 
-  // ---- BL staging (see the comment above the kernel) ----
+  // ---- staging by buffer LDS-DMA loads (see the comment above the kernel) ----
   constexpr unsigned SENT = 0xFFFFFFF0u;  // beyond every descriptor's range
   unsigned abase[4], amask[4], avo[4], wvo[NWROW];
-  int t_rd = 0, t_rh = 0, t_rw = 0, s_wk = 0;  // uniform: current tap, byte offset of its weights in a packed row
+  int s_wk = 0;  // uniform: byte offset of the current tap's weights in a packed row
   const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<bf16*>(src), 0, (int)((unsigned)(g.N * g.Di * g.Hi * g.Wi) * (unsigned)g.ldi * 2u), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<bf16*>(wgt), 0, (int)((unsigned)g.Co * (unsigned)g.ldw * 2u), 0x00020000);
 
-  auto stage_bl = [&](int buf) {
-    const int tile_m = s_tile / tiles_n, tile_n = s_tile - tile_m * tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * TN_;
-    if (s_kt == 0) {
+  auto stage_a_bl = [&](bf16* sA, KCursor& c) {
+    if (c.kt == 0) {
+      const int m0 = (c.tile / tiles_n) * BM;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const RowPos r = decode_row<MODE>(g, m0 + lrow + 32 * i);  // rows beyond M: coordinates far outside
         abase[i] = (unsigned)((((r.n * g.Di + r.d0) * g.Hi + r.h0) * g.Wi + r.w0) * g.ldi * 2 + lchunk * 16);
         amask[i] = tap_mask<MODE>(g, r);
       }
+    }
+    if (c.cb == 0) {
+      int toff = ((c.rd * g.Hi + c.rh) * g.Wi + c.rw) * g.ldi * 2;
+      if (MODE != 0) toff = -toff;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) avo[i] = ((amask[i] >> c.tap) & 1u) ? abase[i] + (unsigned)toff : SENT;
+    }
+    const int kb = c.cb * (BK * 2);  // byte advance inside the tap: the instructions' scalar offset
+    const bool dead = ktail && c.cb * BK + lchunk * 8 >= g.Ci;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(sA + (32 * i + 8 * wave) * BK), 16,
+                                               (int)(dead ? SENT : avo[i]), kb, 0, 0);
+    advance(c);
+  };
+  auto stage_w_bl = [&](bf16* sW, KCursor& c) {
+    if (c.kt == 0) {
+      const int tile_m = c.tile / tiles_n, n0 = (c.tile - tile_m * tiles_n) * TN_;
 #pragma unroll
       for (int i = 0; i < NWROW; ++i) {
         const int co = n0 + lrow + 32 * i;
         wvo[i] = co < g.Co ? (unsigned)(co * g.ldw * 2 + lchunk * 16) : SENT;
       }
-      tap = 0;
-      cb = 0;
-      t_rd = t_rh = t_rw = 0;
     }
-    if (cb == 0) {
-      int toff = ((t_rd * g.Hi + t_rh) * g.Wi + t_rw) * g.ldi * 2;
-      if (MODE != 0) toff = -toff;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) avo[i] = ((amask[i] >> tap) & 1u) ? abase[i] + (unsigned)toff : SENT;
-      s_wk = MODE == 2 ? ((t_rd * g.wt_kh + g.wt_h0 + g.wt_hs * t_rh) * g.wt_kw + g.wt_w0 + g.wt_ws * t_rw) * g.Ci * 2
-                       : tap * g.Ci * 2;
-    }
-    bf16* sA = smem + buf * (BM + TN_) * BK;
-    bf16* sW = sA + BM * BK;
-    const int kb = cb * (BK * 2);  // byte advance inside the tap: the instructions' scalar offset
-    // this thread's chunk of a partial last k-tile (single-tap layers whose channel count is no multiple of BK)
-    const bool dead = ktail && cb * BK + lchunk * 8 >= g.Ci;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(sA + (32 * i + 8 * wave) * BK), 16,
-                                               (int)(dead ? SENT : avo[i]), kb, 0, 0);
+    if (c.cb == 0)
+      s_wk = MODE == 2 ? ((c.rd * g.wt_kh + g.wt_h0 + g.wt_hs * c.rh) * g.wt_kw + g.wt_w0 + g.wt_ws * c.rw) * g.Ci * 2
+                       : c.tap * g.Ci * 2;
+    const int kb = c.cb * (BK * 2);
+    const bool dead = ktail && c.cb * BK + lchunk * 8 >= g.Ci;
 #pragma unroll
     for (int i = 0; i < NWROW; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(sW + (32 * i + 8 * wave) * BK), 16,
                                                (int)(dead ? SENT : wvo[i]), s_wk + kb, 0, 0);
-    if (++cb == ncb) {
-      cb = 0;
-      ++tap;
-      if (++t_rw == g.kw) {
-        t_rw = 0;
-        if (++t_rh == g.kh) {
-          t_rh = 0;
-          ++t_rd;
-        }
-      }
-    }
-    if (++s_kt == nk) {
-      s_kt = 0;
-      s_tile += G;
-    }
+    advance(c);
   };
-#define VC_STAGE_ANY(buf)          \
-  do {                             \
-    if constexpr (BL) stage_bl(buf); \
-    else stage(buf);               \
+#define VC_STAGE_A(buf)                   \
+  do {                                    \
+    if constexpr (BL) stage_a_bl(buf, ca); \
+    else stage_a_gl(buf, ca);             \
+  } while (0)
+#define VC_STAGE_W(buf)                   \
+  do {                                    \
+    if constexpr (BL) stage_w_bl(buf, cw); \
+    else stage_w_gl(buf, cw);             \
   } while (0)
 
   f32x4 acc[WI][4];
@@ -882,9 +890,9 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
 
   const int l15 = lane & 15, q = lane >> 4, x = (l15 >> 1) & 7;
   const int c0 = ((q ^ x) << 3), c1 = (((q ^ x) ^ 4) << 3);
-  const int aoff = (wm * 64 + l15) * BK, woff = BM * BK + (wn * (WI * 16) + l15) * BK;
+  const int aoff = (wm * 64 + l15) * BK, woff = (wn * (WI * 16) + l15) * BK;
 
-  auto compute = [&](const bf16* tile) {
+  auto compute = [&](const bf16* tA, const bf16* tW) {
     // all fragments of the k-tile are requested before the first product, so that one LDS round trip is exposed
     // per k-tile instead of one per group of products
     bf16x8 wf[2][WI], af[2][4];
@@ -892,9 +900,9 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
     for (int ks = 0; ks < 2; ++ks) {
       const int cc = ks ? c1 : c0;
 #pragma unroll
-      for (int i = 0; i < WI; ++i) wf[ks][i] = *reinterpret_cast<const bf16x8*>(tile + woff + cc + i * 16 * BK);
+      for (int i = 0; i < WI; ++i) wf[ks][i] = *reinterpret_cast<const bf16x8*>(tW + woff + cc + i * 16 * BK);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>(tile + aoff + cc + i * 16 * BK);
+      for (int i = 0; i < 4; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>(tA + aoff + cc + i * 16 * BK);
     }
     __builtin_amdgcn_sched_barrier(0);  // keep the requests ahead of the products
 #pragma unroll
@@ -908,18 +916,28 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
 
   // multiply state
   int c_tile = vblock, c_kt = 0;
-  auto finish_ktile = [&](bf16* cbuf) {
+  auto finish_ktile = [&](bf16* tA, bf16* tW) {
     if (++c_kt == nk) {  // output tile complete
       const int tile_m = c_tile / tiles_n, tile_n = c_tile - tile_m * tiles_n;
       if (out_f32) {
         nt_epilogue<MODE, WI>(g, acc, tile_m * BM, tile_n * TN_, wm, wn, lane, bias, out, relu, out_f32, beta);
       } else {
-        // the buffer that was just multiplied is free once every wave has finished reading it (LDS reads only:
-        // the stage in flight keeps streaming while the tile is written out)
+        // the k-tile that was just multiplied is free once every wave has finished reading it (LDS reads only:
+        // the stages in flight keep streaming while the tile is written out); a wave's private image of its part
+        // of the output goes into the source k-tile, or into the weight k-tile when the source one is full
         lds_barrier();
-        nt_epilogue_lds<MODE, WI, EPI>(g, acc, tile_m * BM, tile_n * TN_, wm, wn, lane, bias,
-                                        reinterpret_cast<bf16*>(out), relu, beta, cbuf + wave * (64 * WI * 16),
-                                        bn_partial, tail_y, tail_bits);
+        constexpr int PW = 64 * WI * 16;
+        bf16* img = wave * PW < ASZ ? tA + wave * PW : tW + (wave * PW - ASZ);
+        // two copies of the epilogue: a bias load (to registers) makes the compiler wait for every load in flight,
+        // the staged k-tiles included, and a shared copy would wait on the bias-free path too
+        if (bias || (EPI != EPI_NONE && EPI != EPI_BN_TAIL))  // (the other epilogues are register-bound: one copy)
+          nt_epilogue_lds<MODE, WI, EPI, true>(g, acc, tile_m * BM, tile_n * TN_, wm, wn, lane, bias,
+                                               reinterpret_cast<bf16*>(out), relu, beta, img, bn_partial, tail_y,
+                                               tail_bits);
+        else
+          nt_epilogue_lds<MODE, WI, EPI, false>(g, acc, tile_m * BM, tile_n * TN_, wm, wn, lane, nullptr,
+                                                reinterpret_cast<bf16*>(out), relu, beta, img, bn_partial, tail_y,
+                                                tail_bits);
       }
 #pragma unroll
       for (int i = 0; i < WI; ++i)
@@ -930,22 +948,58 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
     }
   };
 
-  if (vblock < ntiles) VC_STAGE_ANY(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  while (c_tile < ntiles) {
-    if (s_tile < ntiles) VC_STAGE_ANY(1);
-    compute(smem);
-    finish_ktile(smem);
+  if constexpr (NA == 2) {
+    // one k-tile of lead for both operands; every barrier waits for everything outstanding
+    if (vblock < ntiles) {
+      VC_STAGE_A(sA0);
+      VC_STAGE_W(sW0);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (c_tile >= ntiles) break;
-    if (s_tile < ntiles) VC_STAGE_ANY(0);
-    compute(smem + STAGE);
-    finish_ktile(smem + STAGE);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    int ib = 0;
+    while (c_tile < ntiles) {
+      if (ca.tile < ntiles) {
+        VC_STAGE_A(sA0 + (ib ^ 1) * ASZ);
+        VC_STAGE_W(sW0 + (ib ^ 1) * WSZ);
+      }
+      compute(sA0 + ib * ASZ, sW0 + ib * WSZ);
+      finish_ktile(sA0 + ib * ASZ, sW0 + ib * WSZ);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      ib ^= 1;
+    }
+  } else {
+    // Iteration k multiplies k-tile k while the weights of k + 1 and the source rows of k + 2 stream in.  The source
+    // rows are requested LAST, so "at most 4 loads outstanding" (a thread stages 4 source rows per k-tile) means that
+    // everything for k + 1 has landed; the barrier then makes every wave's share of it visible.  Buffers are reused
+    // one iteration after their last read, behind that barrier.  Stores and loads of the epilogue may also be
+    // outstanding at the wait: loads complete in order among themselves, so the bound still covers the staged ones.
+    bool an = false;
+    if (ca.tile < ntiles) VC_STAGE_A(sA0);
+    if (cw.tile < ntiles) VC_STAGE_W(sW0);
+    if (ca.tile < ntiles) {
+      VC_STAGE_A(sA0 + ASZ);
+      an = true;
+    }
+    if (an) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    int ia = 0, iw = 0;
+    while (c_tile < ntiles) {
+      if (cw.tile < ntiles) VC_STAGE_W(sW0 + (iw ^ 1) * WSZ);
+      an = ca.tile < ntiles;
+      if (an) VC_STAGE_A(sA0 + (ia == 0 ? 2 : ia - 1) * ASZ);
+      compute(sA0 + ia * ASZ, sW0 + iw * WSZ);
+      finish_ktile(sA0 + ia * ASZ, sW0 + iw * WSZ);
+      if (an) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      lds_barrier();
+      ia = ia == 2 ? 0 : ia + 1;
+      iw ^= 1;
+    }
   }
+#undef VC_STAGE_A
+#undef VC_STAGE_W
 }
 
 // ----------------------------------------------------------------------------
@@ -1600,6 +1654,15 @@ int use_bl() {
   return v;
 }
 
+// VC_NT_RING = 2 | 3: staged source k-tiles of the persistent kernel (A/B measurements); default 3
+int nt_ring() {
+  static const int v = [] {
+    const char* e = getenv("VC_NT_RING");
+    return (e && atoi(e) == 2) ? 2 : 3;
+  }();
+  return v;
+}
+
 // geometries the buffer-load staging covers (see igemm_nt_persist_kernel)
 bool bl_eligible(const ConvGeom& g, int mode) {
   // Measured on the ResNet-50 layer table: 3x3 layers gain 4-18 % (forward 64 -> 64: 0.267 -> 0.256 ms, its data
@@ -1617,14 +1680,26 @@ template <int MODE, int TN, int EPI>
 void launch_persist(const ConvGeom& g, int grid, hipStream_t stream, const void* src, const void* wgt, const float* bias,
                     void* out, int relu, int out_f32, int beta, int ntiles, float* bn_partial, const void* tail_y,
                     const uint8_t* tail_bits) {
-  if (bl_eligible(g, MODE))
-    hipLaunchKernelGGL((igemm_nt_persist_kernel<MODE, TN, EPI, true>), dim3(grid), dim3(NTHR), 0, stream, g,
-                       (const bf16*)src, (const bf16*)wgt, bias, out, relu, out_f32, beta, ntiles, bn_partial,
-                       (const bf16*)tail_y, tail_bits);
-  else
-    hipLaunchKernelGGL((igemm_nt_persist_kernel<MODE, TN, EPI, false>), dim3(grid), dim3(NTHR), 0, stream, g,
-                       (const bf16*)src, (const bf16*)wgt, bias, out, relu, out_f32, beta, ntiles, bn_partial,
-                       (const bf16*)tail_y, tail_bits);
+#define VC_PERSIST_LAUNCH(BL_, NA_)                                                                                 \
+  hipLaunchKernelGGL((igemm_nt_persist_kernel<MODE, TN, EPI, BL_, NA_>), dim3(grid), dim3(NTHR), 0, stream, g,       \
+                     (const bf16*)src, (const bf16*)wgt, bias, out, relu, out_f32, beta, ntiles, bn_partial,         \
+                     (const bf16*)tail_y, tail_bits)
+  const bool bl = bl_eligible(g, MODE);
+  // Three staged source k-tiles pay where the source streams from HBM into wide tiles: measured on the ResNet-50 layer
+  // table, 1x1 layers of 256..1024 channels at 28 x 28 and 14 x 14 gain 5-12 % (forward and data gradient); the
+  // 64-channel tile loses a third (64 KiB of LDS: two blocks per CU instead of three), multi-tap layers lose 5 % (their
+  // source re-reads come out of L2) and the 7 x 7 layers 3 %, so those keep two.
+  bool deep = false;
+  if constexpr (TN == 128 && EPI == EPI_NONE) deep = nt_ring() == 3 && !bl && g.M >= 50000;
+  if constexpr (TN == 128 && EPI == EPI_NONE) {
+    if (deep) {
+      VC_PERSIST_LAUNCH(false, 3);
+      return;
+    }
+  }
+  if (bl) VC_PERSIST_LAUNCH(true, 2);
+  else VC_PERSIST_LAUNCH(false, 2);
+#undef VC_PERSIST_LAUNCH
 }
 
 template <int MODE>
