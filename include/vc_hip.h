@@ -66,6 +66,15 @@ int vc_conv_dgrad(const int* desc, int dtype, const void* dy, int lddy, const vo
 int vc_conv_dgrad_bn_tail_supported(const int* desc, int dtype);
 int vc_conv_dgrad_bn_tail(const int* desc, int dtype, const void* dy, const void* w_packed_t, void* dx, int beta,
                           const void* tail_y, const uint8_t* tail_bits, float* bn_partial, vc_stream_t stream);
+/* vc_conv_dgrad (bf16, stride 1, dense rows) whose result is the gradient of a = relu(bn(y)) inside a block (conv ->
+ * BatchNorm -> ReLU -> conv: torchvision Bottleneck.forward conv1/bn1/conv2/bn2/conv3, EncoderCNN's conv blocks,
+ * model_components.py:86-101) with a consumed by this convolution alone: the epilogue zeroes dx where
+ * y * scale + shift <= 0 (stat = [4][G][ci] fp32: mean, invstd, scale, shift of the BatchNorm, one group per
+ * rows_per_group consecutive rows, a multiple of 64) and writes per 64-row slab the sums of dz = dx and of dz * y to
+ * bn_partial [M/64][2][ci]; vc_bn_bwd_sums_from_partial turns them into the BatchNorm backward reductions. */
+int vc_conv_dgrad_bn_pre_supported(const int* desc, int dtype, int rows_per_group);
+int vc_conv_dgrad_bn_pre(const int* desc, int dtype, const void* dy, const void* w_packed_t, void* dx, const void* y,
+                         const float* stat, int rows_per_group, float* bn_partial, vc_stream_t stream);
 /* fc1 of a Swin / ViT MLP (timm Mlp: fc1 -> GELU -> fc2, created at model_components.py:254, 412): y = conv(x) + bias
  * and y_gelu = gelu(y) written by the same epilogue, so the activation is not a pass of its own.  Same geometries
  * as vc_conv_fwd_residual (vc_conv_epilogue_side_supported(desc, dtype, 0)). */

@@ -339,3 +339,55 @@ def test_mfma_kernels_at_bench_geometries(cuda, case):
     torch.cuda.synchronize()
     assert _rel(dw, dwn) < tol
     assert _rel(db, dy.float().sum(dim=(0, 1, 2, 3))) < tol
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(4, 16, 16, 64, 64, 1, 2), (2, 8, 32, 256, 128, 1, 1), (4, 16, 16, 64, 64, 3, 2),
+                                   (2, 16, 16, 128, 192, 3, 1)])
+def test_conv_dgrad_with_bn_pre(cuda, shape):
+    """vc_conv_dgrad_bn_pre (the data gradient whose result is the gradient of relu(bn(y))): the stored gradient equals
+    vc_conv_dgrad masked by y * scale + shift > 0 (bit-exact), the slab sums equal sums over the stored values, and
+    vc_bn_bwd_sums_from_partial reproduces vc_bn_bwd_reduce's reductions per group."""
+    from video_classification_amd import _lib as L
+    N, H, W, Cin, Cmid, k, G = shape  # forward layer: k x k convolution Cin -> Cmid, stride 1; dx has Cin channels
+    g = torch.Generator().manual_seed(12)
+    M = N * H * W
+    rpg = M // G
+    taps = k * k
+    dy = torch.randn(M, Cmid, generator=g).to(cuda, torch.bfloat16)
+    wt = (torch.randn(Cin, taps, Cmid, generator=g) * 0.1).to(cuda, torch.bfloat16)  # data-gradient pack [ci][taps][co]
+    y = (torch.randn(M, Cin, generator=g) * 2 + 0.3).to(cuda, torch.bfloat16)
+    stat = torch.randn(4, G, Cin, generator=g).to(cuda)
+    stat[1] = stat[1].abs() + 0.5
+    desc = L.int_array([N, 1, H, W, Cin, 1, H, W, Cmid, 1, k, k, 1, 1, 1, 0, k // 2, k // 2])
+    assert L.query("vc_conv_dgrad_bn_pre_supported", desc, 1, rpg) == 1
+    assert L.query("vc_conv_dgrad_bn_pre_supported", desc, 1, rpg + 8) == 0
+    slabs = M // 64
+    dx0 = torch.empty(M, Cin, device=cuda, dtype=torch.bfloat16)
+    dx1 = torch.empty_like(dx0)
+    part = torch.full((slabs, 2, Cin), float("nan"), device=cuda)
+    L.call("vc_conv_dgrad", desc, 1, L.ptr(dy), 0, L.ptr(wt), L.ptr(dx0), 0, 0, 0, L.stream())
+    L.call("vc_conv_dgrad_bn_pre", desc, 1, L.ptr(dy), L.ptr(wt), L.ptr(dx1), L.ptr(y), L.ptr(stat), rpg, L.ptr(part),
+           L.stream())
+    torch.cuda.synchronize()
+    yf = y.float().view(G, rpg, Cin)
+    pos = (torch.addcmul(stat[3].unsqueeze(1), yf, stat[2].unsqueeze(1)) > 0).view(M, Cin)
+    # (the kernel uses a fused multiply-add: decisions can differ from the two-rounding form only at exact ties)
+    dz_ref = torch.where(pos, dx0.float(), torch.zeros((), device=cuda))
+    diff = (dx1.float() != dz_ref)
+    assert diff.float().mean().item() < 1e-5, diff.sum().item()
+    zp = dx1.float().view(slabs, 64, Cin)
+    ref = torch.stack([zp.sum(1), (zp * y.float().view(slabs, 64, Cin)).sum(1)], 1)
+    assert not torch.isnan(part).any()
+    assert _rel(part.cpu(), ref.cpu()) < 1e-5
+    sa = torch.zeros(2, G, Cin, device=cuda)
+    sb = torch.zeros(2, G, Cin, device=cuda)
+    L.call("vc_bn_bwd_sums_from_partial", L.ptr(part), L.ptr(stat[0]), L.ptr(stat[1]), L.ptr(sa[0]), L.ptr(sa[1]), G,
+           rpg // 64, Cin, L.stream())
+    L.call("vc_bn_bwd_reduce", 1, L.ptr(y), L.ptr(dx0), L.ptr(None), L.ptr(stat[0]), L.ptr(stat[1]), L.ptr(stat[2]),
+           L.ptr(stat[3]), L.ptr(sb[0]), L.ptr(sb[1]), G, rpg, Cin, 1, L.stream())
+    torch.cuda.synchronize()
+    assert _rel(sa[0].cpu(), sb[0].cpu()) < 1e-4
+    assert _rel(sa[1].cpu(), sb[1].cpu()) < 1e-3  # sum dz*y - mean*sum dz against sum dz*(y - mean): cancellation
+
+
+

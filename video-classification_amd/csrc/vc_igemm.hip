@@ -517,7 +517,10 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_fast_kernel(ConvGeom g, cons
 // EPI_GELU_BWD: out = result * gelu'(tail_y) (the gradient through a GELU whose input tail_y was kept).
 // EPI_GELU_DUAL: out = result, and gelu(result as stored) goes to a second tensor of the same layout whose address
 // arrives in tail_y (the only mode that writes through that pointer).
-constexpr int EPI_NONE = 0, EPI_BN_TAIL = 1, EPI_RESIDUAL = 2, EPI_GELU_BWD = 3, EPI_GELU_DUAL = 4;
+constexpr int EPI_NONE = 0, EPI_BN_TAIL = 1, EPI_RESIDUAL = 2, EPI_GELU_BWD = 3, EPI_GELU_DUAL = 4, EPI_BN_PRE = 5;
+// EPI_BN_PRE: the tile is the gradient of relu(bn(y)); `bias` carries the BatchNorm's [4][G][Co] table (mean, invstd,
+// scale, shift per group of `relu` = rows-per-group rows), tail_y = y.  The epilogue zeroes the gradient where
+// y * scale + shift <= 0 and writes the slab sums of dz and dz * y, as EPI_BN_TAIL does from recorded decisions.
 __device__ __forceinline__ float gelu_dev(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
 __device__ __forceinline__ float gelu_grad_dev(float x) {  // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
@@ -539,7 +542,7 @@ __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[
   for (int i = 0; i < WI; ++i) {
     const int col = i * 16 + q * 4;  // channel inside the wave's WC
     float b[4] = {0.f, 0.f, 0.f, 0.f};
-    if (HAS_BIAS && bias) {
+    if (HAS_BIAS && bias && EPI != EPI_BN_PRE) {
       const int co = n0 + wn * WC + col;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
@@ -552,7 +555,7 @@ __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         v[r] = acc[i][j][r] + b[r];
-        if (relu && !beta) v[r] = fmaxf(v[r], 0.f);
+        if (relu && !beta && EPI != EPI_BN_PRE) v[r] = fmaxf(v[r], 0.f);
       }
       const int chunk = (col >> 3) ^ (row & (NCH - 1));
       *reinterpret_cast<bf16x4*>(stage_buf + row * WC + chunk * 8 + (col & 7)) =
@@ -572,7 +575,19 @@ __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[
   bf16x8 oldv[NIT];
   bf16* orow[NIT];
   constexpr bool TAIL = EPI == EPI_BN_TAIL;
+  constexpr bool PRE = EPI == EPI_BN_PRE;
   constexpr bool SIDE_IN = EPI != EPI_NONE && EPI != EPI_GELU_DUAL;  // tail_y is read
+  float psc[PRE ? 8 : 1], psh[PRE ? 8 : 1];
+  if (PRE) {  // host guarantees vec, beta == 0 and 64-row slabs inside one group
+    const int rpg = relu, G = g.M / rpg;
+    const int ms = m0 + wm * 64;
+    const int gi = ms < g.M ? ms / rpg : 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      psc[e] = co + e < g.Co ? bias[(size_t)(2 * G + gi) * g.Co + co + e] : 0.f;
+      psh[e] = co + e < g.Co ? bias[(size_t)(3 * G + gi) * g.Co + co + e] : 0.f;
+    }
+  }
   bf16x8 tyv[SIDE_IN ? NIT : 1];
   unsigned tbits[TAIL ? NIT : 1];
 #pragma unroll
@@ -596,7 +611,7 @@ __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[
     const int row = it * RPI + rr;
     const int m = m0 + wm * 64 + row;
     bf16x8 v = *reinterpret_cast<const bf16x8*>(stage_buf + row * WC + ((ch ^ (row & (NCH - 1))) << 3));
-    if (!TAIL && bn_partial && m < g.M) {
+    if (!TAIL && !PRE && bn_partial && m < g.M) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float t = (float)v[e];
@@ -614,6 +629,18 @@ __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[
         const float dz = (float)v[e];
         ps[e] += dz;
         pq[e] = fmaf(dz, (float)tyv[it][e], pq[e]);
+      }
+      if (op) *reinterpret_cast<bf16x8*>(op) = v;
+    } else if (PRE) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float yy = (float)tyv[it][e];
+        v[e] = fmaf(yy, psc[e], psh[e]) > 0.f ? v[e] : (bf16)0.f;
+        const float dz = (float)v[e];  // rows beyond M: y was read as zero and dz counts for nothing (not stored)
+        if (m < g.M) {
+          ps[e] += dz;
+          pq[e] = fmaf(dz, yy, pq[e]);
+        }
       }
       if (op) *reinterpret_cast<bf16x8*>(op) = v;
     } else if (EPI == EPI_GELU_DUAL) {  // host guarantees vec and beta == 0
@@ -914,7 +941,9 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][i], af[ks][j], acc[i][j], 0, 0, 0);
   };
 
-  // multiply state
+  // multiply state.  (Loading an epilogue's side tensor -- EPI_BN_TAIL / BN_PRE / RESIDUAL / GELU_BWD -- ahead of the
+  // tile's last k-tile, to hide its latency behind the products, measured SLOWER: 32 more live registers push the
+  // 128-wide kernels to the 256-register limit and the 64-wide ones out of their third block per CU.)
   int c_tile = vblock, c_kt = 0;
   auto finish_ktile = [&](bf16* tA, bf16* tW) {
     if (++c_kt == nk) {  // output tile complete
@@ -1857,6 +1886,41 @@ int vc_conv_dgrad_bn_tail(const int* desc, int dtype, const void* dy, const void
   launch_persist<1, 128, EPI_BN_TAIL>(g, grid, stream, dy, w_packed_t, nullptr, dx, 0, 0, beta, tiles, bn_partial, tail_y,
                                       tail_bits);
   VC_LAUNCH_CHECK("vc_conv_dgrad_bn_tail");
+  return VC_OK;
+}
+
+// Stride-1 bf16 data gradient whose result is the gradient of relu(bn(y)) with y of the result's shape: the epilogue
+// masks it with the ReLU decisions recomputed from y and the BatchNorm's scale / shift (stat = [4][G][ci]: mean,
+// invstd, scale, shift; group = rows_per_group consecutive rows, a multiple of 64) and writes bn_partial
+// [M/64][2][ci] = per 64-row slab the sums of dz and dz * y, from which vc_bn_bwd_sums_from_partial forms the
+// BatchNorm backward reductions: the separate reduction pass over (dx, y) is not needed.
+int vc_conv_dgrad_bn_pre_supported(const int* desc, int dtype, int rows_per_group) {
+  ConvGeom g;
+  if (fill_geom(g, desc, 1, "vc_conv_dgrad_bn_pre_supported")) return 0;
+  return (nt_persist_eligible(g, dtype) && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.Co % 8 == 0 && g.ldc == g.Co &&
+          rows_per_group > 0 && rows_per_group % 64 == 0 && g.M % rows_per_group == 0) ? 1 : 0;
+}
+
+int vc_conv_dgrad_bn_pre(const int* desc, int dtype, const void* dy, const void* w_packed_t, void* dx, const void* y,
+                         const float* stat, int rows_per_group, float* bn_partial, hipStream_t stream) {
+  ConvGeom g;
+  int rc = fill_geom(g, desc, 1, "vc_conv_dgrad_bn_pre");
+  if (rc) return rc;
+  VC_CHECK_ARG(dy && w_packed_t && dx && y && stat && bn_partial, "vc_conv_dgrad_bn_pre: null pointer");
+  VC_CHECK_SHAPE(vc_conv_dgrad_bn_pre_supported(desc, dtype, rows_per_group) == 1,
+                 "vc_conv_dgrad_bn_pre: unsupported geometry (ask vc_conv_dgrad_bn_pre_supported)");
+  if (g.Co <= nt_narrow()) {
+    const int t64 = ceil_div(g.M, BM) * ceil_div(g.Co, 64);
+    const int grid = t64 < nt_persist_blocks() * 3 / 2 ? t64 : nt_persist_blocks() * 3 / 2;
+    launch_persist<1, 64, EPI_BN_PRE>(g, grid, stream, dy, w_packed_t, stat, dx, rows_per_group, 0, 0, t64, bn_partial,
+                                      y, nullptr);
+  } else {
+    const int tiles = ceil_div(g.M, BM) * ceil_div(g.Co, BN);
+    const int grid = tiles < nt_persist_blocks() ? tiles : nt_persist_blocks();
+    launch_persist<1, 128, EPI_BN_PRE>(g, grid, stream, dy, w_packed_t, stat, dx, rows_per_group, 0, 0, tiles,
+                                       bn_partial, y, nullptr);
+  }
+  VC_LAUNCH_CHECK("vc_conv_dgrad_bn_pre");
   return VC_OK;
 }
 

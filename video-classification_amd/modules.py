@@ -124,8 +124,11 @@ class Bottleneck(nn.Module):
             # evaluated before conv1 so that its backward runs after conv1's: the strided 1x1 data gradient then
             # only ADDS into the pixels it reaches instead of also zero-filling the rest of the buffer
             idt = ops.conv_bn(x, self.downsample[0].weight, self.downsample[1], T, None, 1, (1, s, s), 0, join=join)
-        a = ops.conv_bn(x, self.conv1.weight, self.bn1, T, relu=True, join=join)
-        a = ops.conv_bn(a, self.conv2.weight, self.bn2, T, None, (1, 3, 3), (1, s, s), (0, 1, 1), relu=True)
+        # conv1 -> conv2 -> conv3 is a chain: each activation has one consumer, whose data-gradient kernel also
+        # does the backward reductions of the BatchNorm in front of it
+        a = ops.conv_bn(x, self.conv1.weight, self.bn1, T, relu=True, join=join, single_use=True)
+        a = ops.conv_bn(a, self.conv2.weight, self.bn2, T, None, (1, 3, 3), (1, s, s), (0, 1, 1), relu=True,
+                        single_use=True)
         # The block's output feeds the next block through a GradJoin, the average pool or a caller's own op, each of
         # which hands back a gradient tensor nobody else holds: bn3's backward may mask it in place.
         if idt is not None:

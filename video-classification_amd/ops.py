@@ -196,6 +196,7 @@ class _Conv(torch.autograd.Function):
                 pre_gelu=False, want_gelu=False, gelu_x=None):
         _require_cuda(x, "conv")
         ctx.join = join
+        ctx.bn_pre = getattr(x, "_vc_bn_pre", None) if (join is None and FUSE_BN_PRE) else None
         # the slab-sum output never carries a gradient: do not let autograd fill a zero tensor of its size per call
         ctx.set_materialize_grads(False)
         x = x.contiguous()
@@ -344,6 +345,7 @@ class _Conv(torch.autograd.Function):
             acc = join is not None and join.buf is not None
             dx = join.buf if acc else torch.empty_like(x)
             tail = join.tail if (join is not None and join.pending == 1 and FUSE_BN_TAIL) else None
+            pre = ctx.bn_pre
             gelu_done = False
             if (ctx.pre is not None and not acc and FUSE_EPILOGUE_SIDE and
                     L.query("vc_conv_epilogue_side_supported", desc, code, 1) == 1):
@@ -361,6 +363,17 @@ class _Conv(torch.autograd.Function):
                     "vc_conv_dgrad_bn_tail", desc, code, L.ptr(dy), L.ptr(wt), L.ptr(dx), int(acc), L.ptr(tail.y),
                     L.ptr(tail.bits), L.ptr(partial), L.stream()))
                 tail.partial = partial
+            elif (pre is not None and not acc and ctx.pre is None and tuple(pre.y.shape) == tuple(dx.shape) and
+                    pre.y.dtype == dx.dtype and
+                    L.query("vc_conv_dgrad_bn_pre_supported", desc, code, pre.rpg) == 1):
+                # x = relu(bn(y)) feeds this layer alone: the epilogue applies the ReLU decisions and writes the slab
+                # sums of that BatchNorm's backward reductions
+                M = dx.numel() // dx.shape[-1]
+                partial = torch.empty(M // 64, 2, dx.shape[-1], device=dx.device, dtype=torch.float32)
+                _timed("conv_dgrad", ctx.flops, lambda: L.call(
+                    "vc_conv_dgrad_bn_pre", desc, code, L.ptr(dy), L.ptr(wt), L.ptr(dx), L.ptr(pre.y), L.ptr(pre.stat),
+                    pre.rpg, L.ptr(partial), L.stream()))
+                pre.partial = partial
             else:
                 _timed("conv_dgrad", ctx.flops, lambda: L.call(
                     "vc_conv_dgrad", desc, code, L.ptr(dy), 0, L.ptr(wt), L.ptr(dx), 0, int(dtype == torch.float32),
@@ -519,6 +532,18 @@ class BNTail:
         self.y = self.bits = self.partial = None
 
 
+class BNPre:
+    """Travels as the attribute ``_vc_bn_pre`` of a = relu(bn(y)) when the caller states that ONE convolution consumes
+    a: that convolution's data-gradient kernel then masks its result with the ReLU decisions (recomputed from y) and
+    leaves the slab sums the BatchNorm backward needs (`partial`), so no reduction pass reads the gradient and y."""
+
+    def __init__(self, y, stat, rpg):
+        self.y, self.stat, self.rpg, self.partial = y, stat, rpg, None
+
+
+# VC_FUSE_BN_PRE=0 keeps the BatchNorm backward reductions inside blocks in their own pass (A/B measurements)
+FUSE_BN_PRE = os.environ.get("VC_FUSE_BN_PRE", "1") != "0"
+
 # VC_FUSE_BN_TAIL=0 keeps the BatchNorm backward reductions of residual blocks in their own pass (A/B measurements)
 FUSE_BN_TAIL = os.environ.get("VC_FUSE_BN_TAIL", "1") != "0"
 
@@ -552,7 +577,7 @@ def conv(x, weight, bias=None, kernel=1, stride=1, padding=0, relu=False, out_f3
 
 
 def conv_bn(x, weight, bn, groups, bias=None, kernel=1, stride=1, padding=0, relu=False, residual=None, join=None,
-            res_join=None, grad_inplace=False, pool=None):
+            res_join=None, grad_inplace=False, pool=None, single_use=False):
     """BatchNorm(conv(x)) (+ residual, ReLU).  In training the convolution's epilogue also writes the slab sums
     the BatchNorm statistics are taken from, where the geometry allows it (otherwise a separate pass reads y)."""
     training = bn.training or bn.running_mean is None
@@ -561,7 +586,7 @@ def conv_bn(x, weight, bn, groups, bias=None, kernel=1, stride=1, padding=0, rel
     if pool is not None:  # (k, s, p) of the max-pool that follows BatchNorm + ReLU
         return batch_norm_relu_pool(y, bn, groups, *pool, partial=partial if partial.numel() else None)
     return batch_norm(y, bn, groups, relu=relu, residual=residual, res_join=res_join,
-                      partial=partial if partial.numel() else None, grad_inplace=grad_inplace)
+                      partial=partial if partial.numel() else None, grad_inplace=grad_inplace, single_use=single_use)
 
 
 def linear(x, weight, bias=None, relu=False, out_f32=False, residual=None, pre_gelu=False, want_gelu=False,
@@ -597,11 +622,12 @@ def _nbt(bn):
 class _BatchNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, gamma, beta, running_mean, running_var, groups, momentum, eps, relu, residual, training,
-                res_join, owner, partial, grad_inplace=False, tail=None):
+                res_join, owner, partial, grad_inplace=False, tail=None, pre=None):
         _require_cuda(y, "batch_norm")
         ctx.res_join = res_join
         ctx.grad_inplace = grad_inplace
         ctx.tail = tail
+        ctx.bn_pre = None
         ctx.owner = owner
         y = y.contiguous()
         C = y.shape[-1]
@@ -644,6 +670,9 @@ class _BatchNorm(torch.autograd.Function):
         else:
             L.call("vc_bn_apply", code, L.ptr(y), L.ptr(stat[2]), L.ptr(stat[3]), L.ptr(res), L.ptr(out), G, rpg, C,
                    int(relu), L.stream())
+        if pre is not None and training and relu and res is None and y.dtype == torch.bfloat16 and rpg % 64 == 0:
+            pre.y, pre.stat, pre.rpg = y, stat, rpg
+            ctx.bn_pre = pre
         ctx.G, ctx.rpg, ctx.C, ctx.relu, ctx.training = G, rpg, C, relu, training
         ctx.has_res = residual is not None
         ctx.gamma, ctx.beta = gamma, beta
@@ -677,6 +706,16 @@ class _BatchNorm(torch.autograd.Function):
             L.call("vc_bn_bwd_apply", code, L.ptr(y), L.ptr(dout), L.ptr(None), L.ptr(stat[0]), L.ptr(stat[1]),
                    L.ptr(stat[2]), L.ptr(stat[3]), L.ptr(s[0]), L.ptr(s[1]), L.ptr(dy), L.ptr(None), G, rpg, C, 0,
                    L.stream())
+        elif ctx.bn_pre is not None and ctx.bn_pre.partial is not None:
+            # the data-gradient kernel that produced dout has masked it and left slab sums of dz and dz * y
+            pre = ctx.bn_pre
+            L.call("vc_bn_bwd_sums_from_partial", L.ptr(pre.partial), L.ptr(stat[0]), L.ptr(stat[1]), L.ptr(s[0]),
+                   L.ptr(s[1]), G, rpg // 64, C, L.stream())
+            pre.partial = None
+            dres = None
+            L.call("vc_bn_bwd_apply", code, L.ptr(y), L.ptr(dout), L.ptr(None), L.ptr(stat[0]), L.ptr(stat[1]),
+                   L.ptr(stat[2]), L.ptr(stat[3]), L.ptr(s[0]), L.ptr(s[1]), L.ptr(dy), L.ptr(None), G, rpg, C, 0,
+                   L.stream())
         else:
             L.call("vc_bn_bwd_reduce", code, L.ptr(y), L.ptr(dout), L.ptr(out), L.ptr(stat[0]), L.ptr(stat[1]),
                    L.ptr(stat[2]), L.ptr(stat[3]), L.ptr(s[0]), L.ptr(s[1]), G, rpg, C, int(ctx.relu), L.stream())
@@ -693,25 +732,32 @@ class _BatchNorm(torch.autograd.Function):
         db = _grad_buf(ctx.beta) if ctx.beta is not None and ctx.beta.requires_grad else None
         L.call("vc_bn_bwd_params", L.ptr(s[0]), L.ptr(s[1]), L.ptr(dg), L.ptr(db), G, C, 3, L.stream())
         _ready(ctx.gamma, ctx.beta)
-        return dy, None, None, None, None, None, None, None, None, dres, None, None, None, None, None, None
+        return dy, None, None, None, None, None, None, None, None, dres, None, None, None, None, None, None, None
 
 
 # VC_BN_INPLACE_MASK=0 keeps the gradient of a residual block's output untouched (A/B measurements)
 BN_INPLACE_MASK = os.environ.get("VC_BN_INPLACE_MASK", "1") != "0"
 
 
-def batch_norm(y, bn, groups, relu=False, residual=None, res_join=None, partial=None, grad_inplace=False):
+def batch_norm(y, bn, groups, relu=False, residual=None, res_join=None, partial=None, grad_inplace=False,
+               single_use=False):
     """bn: an nn.BatchNorm{1,2,3}d module holding the parameters/buffers (its own forward is not used).
     res_join: optional GradJoin shared with the other consumers of `residual`.
     grad_inplace: the caller guarantees that nothing else reads the gradient of this call's output, so the
-    backward pass may overwrite it (relu(bn(y) + residual): the masked gradient replaces it in place)."""
+    backward pass may overwrite it (relu(bn(y) + residual): the masked gradient replaces it in place).
+    single_use: the caller guarantees that the result feeds exactly ONE ops.conv / ops.conv_bn call and nothing else;
+    that layer's data-gradient kernel then also does this BatchNorm's backward reductions (see BNPre)."""
     training = bn.training or bn.running_mean is None
     tail = BNTail() if (grad_inplace and relu and residual is not None and training and torch.is_grad_enabled()) else None
+    pre = BNPre(None, None, 0) if (single_use and relu and residual is None and training and FUSE_BN_PRE and
+                                   torch.is_grad_enabled()) else None
     out = _BatchNorm.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, groups,
                            bn.momentum if bn.momentum is not None else 0.1, bn.eps, relu, residual, training,
-                           res_join, bn, partial, grad_inplace, tail)
+                           res_join, bn, partial, grad_inplace, tail, pre)
     if tail is not None and tail.bits is not None:
         out._vc_bn_tail = tail
+    if pre is not None and pre.y is not None:
+        out._vc_bn_pre = pre
     if training and bn.num_batches_tracked is not None and _nbt(bn) is None:
         bn.num_batches_tracked += groups
     return out
