@@ -66,13 +66,13 @@ def build_workload(args, M, S, oracle=False):
         enc = (O or S).SwinTransformerEncoder(1024, 768, 0.0, 512)
         dec = (O or M).DecoderRNN(512, args.lstm_layers, 512, 256, 0.0, 101)
         return (O or M).SwinTransformerRNNModel(enc, dec), (B, 16, 3, 224, 224), (
-            f"swintransformer-RNN training step: Swin-T encoder (1024/768/512 head) + DecoderRNN({args.lstm_layers}x512), "
+            f"swintransformer-RNN training step: Swin-T encoder (drop_path 0.1, 1024/768/512 head) + DecoderRNN({args.lstm_layers}x512), "
             f"{B} clips/GPU x 16 x 3 x 224 x 224")
     if args.model == "clusterswin":
         enc = (O or S).ClusterSwinEncoder(embed_dim=96, k_tokens=8)
         dec = (O or M).TCG_LSTM(96, 512, 2, 8, 4, 101, 0.1)
         return (O or M).SwinTCGModel(enc, dec), (B, 16, 3, 224, 224), (
-            f"clusterSwin_TCGlstm training step: ClusterSwinEncoder(Swin-T, E=96, k=8) + TCG_LSTM(H=512, L=2, drop 0.1), "
+            f"clusterSwin_TCGlstm training step: ClusterSwinEncoder(Swin-T, drop_path 0.1, E=96, k=8) + TCG_LSTM(H=512, L=2, drop 0.1), "
             f"{B} clips/GPU x 16 x 3 x 224 x 224")
     raise SystemExit(f"unknown --model {args.model}")
 

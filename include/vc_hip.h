@@ -82,12 +82,14 @@ int vc_conv_fwd_gelu_dual(const int* desc, int dtype, const void* x, const void*
                           void* y_gelu, vc_stream_t stream);
 /* GEMM epilogues that read a side tensor of the output's own layout (bf16, dense rows, more than 64 output columns;
  * vc_conv_epilogue_side_supported(desc, dtype, mode: 0 forward, 1 data gradient) says whether a geometry qualifies):
- * vc_conv_fwd_residual: y = conv(x) + bias + residual, out of place -- the x + attn(x) / x + mlp(x) of the Swin blocks
- * (timm SwinTransformerBlock behind model_components.py:254, 412); vc_conv_dgrad_gelu: dx = dgrad * gelu'(pre), the
+ * vc_conv_fwd_residual: y = row_scale * (conv(x) + bias) + residual, out of place -- the x + drop_path(attn(x)) /
+ * x + drop_path(mlp(x)) of the Swin blocks (timm SwinTransformerBlock behind model_components.py:254, 412); row_scale
+ * (nullable = ones) holds one fp32 factor per rows_per_sample consecutive rows, as vc_drop_path_scales writes them; vc_conv_dgrad_gelu: dx = dgrad * gelu'(pre), the
  * gradient through the MLP's GELU taken in the data-gradient GEMM of mlp.fc2 (pre = mlp.fc1's output). */
 int vc_conv_epilogue_side_supported(const int* desc, int dtype, int mode);
 int vc_conv_fwd_residual(const int* desc, int dtype, const void* x, const void* w_packed, const float* bias,
-                         const void* residual, void* y, vc_stream_t stream);
+                         const void* residual, const float* row_scale, int rows_per_sample, void* y,
+                         vc_stream_t stream);
 int vc_conv_dgrad_gelu(const int* desc, int dtype, const void* dy, const void* w_packed_t, const void* pre, void* dx,
                        vc_stream_t stream);
 /* dw_packed (fp32 [co][taps][ci]) is accumulated into with atomics: the caller zeroes it.  dbias (nullable, fp32
@@ -217,6 +219,9 @@ int vc_dropout_bwd(int dtype, const void* dy, const uint8_t* mask, void* dx, int
 /* timm's DropPath (stochastic depth) inside the Swin blocks; backward applies the same call to the gradient */
 int vc_drop_path(int dtype, const void* x, void* out, int64_t n, int64_t elems_per_sample, float p, uint64_t seed,
                  const int64_t* seed_dev, vc_stream_t stream);
+/* the same per-sample factors (0 or 1 / (1 - p)) as a vector scales[samples], for vc_conv_fwd_residual's row_scale */
+int vc_drop_path_scales(float* scales, int samples, float p, uint64_t seed, const int64_t* seed_dev,
+                        vc_stream_t stream);
 
 /* ---- Swin-T window attention / patch merging (timm swin_tiny_patch4_window7_224 behind
  * model_components.py:254, 412).  qkv [B*H*W][3C] in token order; window partition, cyclic shift, relative

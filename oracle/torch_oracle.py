@@ -391,7 +391,17 @@ class SwinBlock(nn.Module):
         self.register_buffer("attn_mask", _shift_mask(res, res, ws, self.shift) if self.shift else None,
                              persistent=False)
 
-    def forward(self, x):  # x: [B, H, W, C]; drop-path is stochastic and therefore 0 in the oracle
+    drop_path = 0.0  # set by SwinT (timm's linear schedule over the blocks)
+
+    def _drop(self, y):
+        """timm's DropPath: in training a sample's branch is zeroed with probability p, else scaled by 1 / (1 - p)."""
+        p = self.drop_path
+        if p == 0.0 or not self.training:
+            return y
+        keep = y.new_empty((y.shape[0],) + (1,) * (y.dim() - 1)).bernoulli_(1.0 - p)
+        return _r(y * (keep / (1.0 - p)))
+
+    def forward(self, x):  # x: [B, H, W, C]
         B, H, W, C = x.shape
         ws = self.ws
         y = _r(self.norm1(x))
@@ -402,8 +412,8 @@ class SwinBlock(nn.Module):
         y = y.view(B, H // ws, W // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, C)
         if self.shift:
             y = torch.roll(y, (self.shift, self.shift), (1, 2))
-        x = _r(x + y)
-        return _r(x + self.mlp(_r(self.norm2(x))))
+        x = _r(x + self._drop(y))
+        return _r(x + self._drop(self.mlp(_r(self.norm2(x)))))
 
 
 class PatchMerging(nn.Module):
@@ -442,7 +452,9 @@ class PatchEmbed(nn.Module):
 class SwinT(nn.Module):
     """swin_tiny_patch4_window7_224 with num_classes=0: returns [B, 768] (LN then mean over tokens)."""
 
-    def __init__(self, img=224, patch=4, dim=96, depths=(2, 2, 6, 2), heads=(3, 6, 12, 24), ws=7):
+    def __init__(self, img=224, patch=4, dim=96, depths=(2, 2, 6, 2), heads=(3, 6, 12, 24), ws=7, drop_path_rate=0.1):
+        # drop_path_rate: timm's SwinTransformer default; timm.create_model(name, pretrained=True, num_classes=0)
+        # (reference model_components.py:254, 412) does not change it.  The parity tests pass 0.
         super().__init__()
         self.patch_embed = PatchEmbed(dim, patch)
         res = img // patch
@@ -450,6 +462,9 @@ class SwinT(nn.Module):
             SwinStage(dim * 2 ** i, res // 2 ** i, depths[i], heads[i], ws, merge=i > 0) for i in range(len(depths))])
         self.num_features = dim * 2 ** (len(depths) - 1)
         self.norm = nn.LayerNorm(self.num_features)
+        blocks = [b for st in self.layers for b in st.blocks]
+        for i, b in enumerate(blocks):
+            b.drop_path = drop_path_rate * i / max(len(blocks) - 1, 1)
         for m in self.modules():
             if isinstance(m, nn.Linear):
                 nn.init.trunc_normal_(m.weight, std=0.02)

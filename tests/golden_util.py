@@ -41,7 +41,7 @@ def conv3d_config():
 # model_components.create_model), so that the reference's OWN ResCNNEncoder / ClusterSwinEncoder code runs
 # unchanged around them; the tests build the same stand-ins to know what the fixtures' keys mean.
 RESNET_STANDIN = dict(arch="tiny", width=8)      # bottleneck trunk [1, 1, 1, 1], 8 stem channels, 256 features
-SWIN_STANDIN = dict(img=56, patch=4, dim=32, depths=(2, 2), heads=(1, 2), ws=7)
+SWIN_STANDIN = dict(img=56, patch=4, dim=32, depths=(2, 2), heads=(1, 2), ws=7, drop_path_rate=0.0)
 
 
 def resnet_standin(weights=None):

@@ -30,6 +30,8 @@ DTYPES = [torch.float32, torch.bfloat16]
 IDS = ["f32", "bf16"]
 
 
+NO_DROP = dict(drop_path_rate=0.0)  # stochastic depth (timm default 0.1) draws random samples: off for parity
+
 def _compare(mine, out_m, loss_m, ref_out, ref_loss, ref_grads, dt, tol_g, cancelled=(), group_tol=None):
     tol_o = 2e-4 if dt == torch.float32 else 4e-2
     out_m = out_m.detach().float().cpu()
@@ -173,7 +175,7 @@ def test_resnet50_crnn_ucf_shape(cuda, dt):
 def _swin_ref(emulate=False):
     from oracle import torch_oracle as O
     torch.manual_seed(12)
-    ref = O.SwinTCGModel(O.ClusterSwinEncoder(embed_dim=96, k_tokens=8), O.TCG_LSTM(96, 512, 2, 8, 4, 101, 0.0))
+    ref = O.SwinTCGModel(O.ClusterSwinEncoder(embed_dim=96, k_tokens=8, swin_kwargs=NO_DROP), O.TCG_LSTM(96, 512, 2, 8, 4, 101, 0.0))
     g = torch.Generator().manual_seed(4321)
     x = torch.randn(4, 16, 3, 224, 224, generator=g)
     y = torch.randint(0, 101, (4, 1), generator=g)
@@ -194,7 +196,7 @@ def test_cluster_swin_tcg_ucf_shape(cuda, dt):
     from video_classification_amd import ops
     from video_classification_amd import swin as S
     sd, x, y, ref_out, ref_loss, ref_grads = _swin_ref()
-    mine = M.SwinTCGModel(S.ClusterSwinEncoder(embed_dim=96, k_tokens=8), M.TCG_LSTM(96, 512, 2, 8, 4, 101, 0.0))
+    mine = M.SwinTCGModel(S.ClusterSwinEncoder(embed_dim=96, k_tokens=8, swin_kwargs=NO_DROP), M.TCG_LSTM(96, 512, 2, 8, 4, 101, 0.0))
     mine.load_state_dict(sd, strict=True)
     mine.to(cuda).set_compute_dtype(dt)
     mine.train()
@@ -222,7 +224,7 @@ def _swin_rnn_ref(emulate=False):
     torch.manual_seed(14)
     # what the reference's factory builds for --model swintransformer-RNN (train.py:256-278 with the Config defaults
     # of models/swintransformer_RNN/UCF101_SwinCRNN_fixed.py:72-80 and create_model, :404-423)
-    ref = O.SwinTransformerRNNModel(O.SwinTransformerEncoder(1024, 768, 0.0, 512), O.DecoderRNN(512, 3, 512, 256, 0.0, 101))
+    ref = O.SwinTransformerRNNModel(O.SwinTransformerEncoder(1024, 768, 0.0, 512, swin_kwargs=NO_DROP), O.DecoderRNN(512, 3, 512, 256, 0.0, 101))
     g = torch.Generator().manual_seed(777)
     B = 6
     x = torch.randn(B, 16, 3, 224, 224, generator=g)
@@ -245,7 +247,7 @@ def test_swin_rnn_ucf_shape(cuda, dt):
     from video_classification_amd import modules as M
     from video_classification_amd import ops
     from video_classification_amd import swin as S
-    mine = M.SwinTransformerRNNModel(S.SwinTransformerEncoder(1024, 768, 0.0, 512), M.DecoderRNN(512, 3, 512, 256, 0.0, 101))
+    mine = M.SwinTransformerRNNModel(S.SwinTransformerEncoder(1024, 768, 0.0, 512, swin_kwargs=NO_DROP), M.DecoderRNN(512, 3, 512, 256, 0.0, 101))
     sd, x, y, ref_out, ref_loss, ref_grads, ref_bufs = _swin_rnn_ref()
     # the oracle's state_dict is taken AFTER its training-mode forward: running statistics start from the defaults
     sd0 = {k: v for k, v in sd.items() if not ("running_" in k or "num_batches" in k)}

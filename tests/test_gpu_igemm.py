@@ -240,7 +240,8 @@ def test_epilogue_side_tensor_forms(cuda):
     y0 = torch.empty(M, N, device=cuda, dtype=torch.float32)
     y1 = torch.empty(M, N, device=cuda, dtype=torch.bfloat16)
     L.call("vc_conv_fwd", desc, 1, L.ptr(x), 0, L.ptr(wf), L.ptr(bias), L.ptr(y0), 0, 0, 1, 0, L.stream())
-    L.call("vc_conv_fwd_residual", desc, 1, L.ptr(x), L.ptr(wf), L.ptr(bias), L.ptr(res), L.ptr(y1), L.stream())
+    L.call("vc_conv_fwd_residual", desc, 1, L.ptr(x), L.ptr(wf), L.ptr(bias), L.ptr(res), L.ptr(None), 0, L.ptr(y1),
+           L.stream())
     torch.cuda.synchronize()
     ref = y0.bfloat16().float() + res.float()  # the kernel parks the bf16-rounded result, then adds in fp32
     assert torch.equal(y1, ref.bfloat16())

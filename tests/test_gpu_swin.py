@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 TOL = {torch.float32: (2e-4, 1e-3), torch.bfloat16: (4e-2, 2e-1)}
 DTYPES = [torch.float32, torch.bfloat16]
 IDS = ["f32", "bf16"]
-SMALL = dict(img=56, patch=4, dim=32, depths=(2, 2), heads=(1, 2), ws=7)  # stages at 14x14 (shifted) and 7x7
+SMALL = dict(img=56, patch=4, dim=32, depths=(2, 2), heads=(1, 2), ws=7, drop_path_rate=0.0)  # stages at 14x14 (shifted) and 7x7
 
 
 class _LinearBackbone(nn.Sequential):
@@ -135,3 +135,75 @@ def test_cluster_swin_encoder_around_standin_backbone(cuda, dt):
     assert G.max_rel(g.detach().cpu(), d["out_g"]) < tol_o
     assert G.max_rel(c.detach().cpu(), d["out_c"]) < tol_o
     G.check_grads(dict(enc.named_parameters()), G.group(d, "g"), tol_g)
+
+
+@pytest.mark.gpu
+def test_residual_epilogue_with_sample_factors(cuda):
+    """vc_conv_fwd_residual with a row scale: y = residual + f[sample] * (x W^T + b), the factors being exactly those
+    vc_drop_path applies for the same seed (0 or 1 / (1 - p) per sample)."""
+    from video_classification_amd import _lib as L
+    import ctypes
+    g = torch.Generator().manual_seed(33)
+    S_, rows, K, N = 12, 49, 192, 192          # 12 samples of 49 rows: sample boundaries inside the 128-row tiles
+    M = S_ * rows
+    x = torch.randn(M, K, generator=g).to(cuda, torch.bfloat16)
+    wf = (torch.randn(N, 1, K, generator=g) * 0.1).to(cuda, torch.bfloat16)
+    bias = torch.randn(N, generator=g).to(cuda)
+    res = torch.randn(M, N, generator=g).to(cuda, torch.bfloat16)
+    desc = L.int_array([M, 1, 1, 1, K, 1, 1, 1, N, 1, 1, 1, 1, 1, 1, 0, 0, 0])
+    p, seed = 0.4, ctypes.c_uint64(12345)
+    scales = torch.empty(S_, device=cuda)
+    L.call("vc_drop_path_scales", L.ptr(scales), S_, p, seed, L.ptr(None), L.stream())
+    ones = torch.ones(M, 8, device=cuda, dtype=torch.bfloat16)
+    kept = torch.empty_like(ones)
+    L.call("vc_drop_path", 1, L.ptr(ones), L.ptr(kept), L.i64(ones.numel()), L.i64(rows * 8), p, seed, L.ptr(None),
+           L.stream())
+    y0 = torch.empty(M, N, device=cuda, dtype=torch.float32)
+    y1 = torch.empty(M, N, device=cuda, dtype=torch.bfloat16)
+    L.call("vc_conv_fwd", desc, 1, L.ptr(x), 0, L.ptr(wf), L.ptr(bias), L.ptr(y0), 0, 0, 1, 0, L.stream())
+    L.call("vc_conv_fwd_residual", desc, 1, L.ptr(x), L.ptr(wf), L.ptr(bias), L.ptr(res), L.ptr(scales), rows, L.ptr(y1),
+           L.stream())
+    torch.cuda.synchronize()
+    sc = scales.cpu()
+    keepf = torch.tensor(1.0) / torch.tensor(1.0 - p)   # fp32, as the kernel computes it
+    assert set(sc.tolist()) <= {0.0, keepf.item()} and 0.0 in sc.tolist() and sc.max() > 0
+    assert torch.equal(kept.float()[:, 0].cpu().view(S_, rows)[:, 0], sc.bfloat16().float())  # same decisions
+    f = scales.repeat_interleave(rows).unsqueeze(1)
+    # the kernel parks the bf16-rounded product and finishes with one fp32 fused multiply-add
+    ref = (res.double() + y0.bfloat16().double() * f.double()).float().bfloat16()
+    bad = (y1 != ref)
+    assert bad.float().mean().item() < 1e-3, bad.sum().item()   # (ties of the double rounding)
+    assert G.max_rel(y1.float().cpu(), ref.float().cpu()) < 1e-3
+
+
+@pytest.mark.gpu
+def test_swin_block_stochastic_depth_fused_equals_unfused(cuda):
+    """A Swin block in training with drop_path 0.5: the fused form (factors applied in the projection / fc2 GEMM
+    epilogues) and the unfused form (scaling pass + add pass) draw the same per-frame decisions from the same seed and
+    give the same output and gradients up to the rounding of the intermediate the unfused form stores."""
+    from video_classification_amd import ops
+    from video_classification_amd.swin import SwinBlock
+    torch.manual_seed(3)
+    blk = SwinBlock(128, 14, 4, 7, 3).to(cuda)
+    F_ = 16
+    x = torch.randn(F_, 14, 14, 128, device=cuda).bfloat16()
+    go = torch.randn(F_, 14, 14, 128, device=cuda).bfloat16()
+    res = {}
+    for fused in (True, False):
+        ops.FUSE_EPILOGUE_SIDE = fused
+        try:
+            ops.manual_seed(77)
+            blk.zero_grad(set_to_none=True)
+            xi = x.clone().requires_grad_(True)
+            out = blk.run(xi, 0.5, True)
+            out.backward(go.clone())
+            torch.cuda.synchronize()
+            res[fused] = [out.detach().float().cpu(), xi.grad.float().cpu()] + \
+                [p.grad.float().cpu() for p in blk.parameters()]
+        finally:
+            ops.FUSE_EPILOGUE_SIDE = True
+    a, b = res[True][0], res[False][0]
+    untouched = ((b - x.float().cpu()).abs().amax(dim=(1, 2, 3)) == 0)   # frames whose two branches were both dropped
+    assert 0 < (a - x.float().cpu()).abs().amax(dim=(1, 2, 3)).eq(0).sum() == untouched.sum() < F_
+    for u, v in zip(res[True], res[False]):
+        assert G.max_rel(u, v) < 2e-2

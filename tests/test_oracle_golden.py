@@ -52,7 +52,7 @@ def test_conv3d():
 
 def test_swin_head_and_frame_loop():
     """The reference's SwinTransformerEncoder.forward with a stand-in backbone (see make_golden.py)."""
-    enc = O.SwinTransformerEncoder(64, 48, 0.0, 32)
+    enc = O.SwinTransformerEncoder(64, 48, 0.0, 32, swin_kwargs=dict(drop_path_rate=0.0))
     enc.swin = nn.Sequential(nn.Flatten(), nn.Linear(3 * 8 * 8, 768))
     _run_component("swin_head_tiny", enc, ["x"])
 

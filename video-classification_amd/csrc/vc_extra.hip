@@ -54,6 +54,14 @@ __global__ void drop_path_kernel(const T* __restrict__ x, T* __restrict__ out, i
   }
 }
 
+// the per-sample factors drop_path_kernel applies, as a vector (for a GEMM epilogue that scales its rows)
+__global__ void drop_path_scales_kernel(float* __restrict__ scales, int samples, uint32_t thresh, float scale,
+                                        uint64_t seed, const int64_t* __restrict__ seed_dev) {
+  if (seed_dev) seed += (uint64_t)*seed_dev * 0xD1B54A32D192ED03ull;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < samples) scales[i] = mix_u32(seed, (uint64_t)i) >= thresh ? scale : 0.f;
+}
+
 // ---------------------------------------------------------------------------
 // TCG-LSTM fusion.  Layouts are time-major: h_s [T][B][2H], h_l [Tl][B][H].
 // Linear interpolation follows F.interpolate(mode='linear', align_corners=False):
@@ -321,6 +329,16 @@ int vc_drop_path(int dtype, const void* x, void* out, int64_t n, int64_t elems_p
              hipLaunchKernelGGL((drop_path_kernel<T>), dim3(ew_grid(n / 8)), dim3(NTHR), 0, stream, (const T*)x,
                                 (T*)out, n / 8, elems_per_sample / 8, thresh, scale, seed, seed_dev);)
   VC_LAUNCH_CHECK("vc_drop_path");
+  return VC_OK;
+}
+
+int vc_drop_path_scales(float* scales, int samples, float p, uint64_t seed, const int64_t* seed_dev,
+                        hipStream_t stream) {
+  VC_CHECK_ARG(scales && samples > 0 && p >= 0.f && p < 1.f, "vc_drop_path_scales: bad argument");
+  const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
+  hipLaunchKernelGGL(drop_path_scales_kernel, dim3((samples + 255) / 256), dim3(256), 0, stream, scales, samples,
+                     thresh, 1.f / (1.f - p), seed, seed_dev);
+  VC_LAUNCH_CHECK("vc_drop_path_scales");
   return VC_OK;
 }
 

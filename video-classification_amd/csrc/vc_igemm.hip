@@ -555,7 +555,7 @@ __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         v[r] = acc[i][j][r] + b[r];
-        if (relu && !beta && EPI != EPI_BN_PRE) v[r] = fmaxf(v[r], 0.f);
+        if (relu && !beta && EPI != EPI_BN_PRE && EPI != EPI_RESIDUAL) v[r] = fmaxf(v[r], 0.f);
       }
       const int chunk = (col >> 3) ^ (row & (NCH - 1));
       *reinterpret_cast<bf16x4*>(stage_buf + row * WC + chunk * 8 + (col & 7)) =
@@ -653,11 +653,14 @@ __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[
       }
     } else if (EPI == EPI_RESIDUAL || EPI == EPI_GELU_BWD) {  // host guarantees vec
       if (op) {
+        // EPI_RESIDUAL with a row scale (stochastic depth): tail_bits carries fp32 scales, one per `relu` rows
+        float rs = 1.f;
+        if (EPI == EPI_RESIDUAL && tail_bits) rs = reinterpret_cast<const float*>(tail_bits)[m / relu];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float t = (float)v[e];
           if (beta) t += (float)oldv[it][e];
-          if (EPI == EPI_RESIDUAL) t += (float)tyv[it][e];
+          if (EPI == EPI_RESIDUAL) t = fmaf(t, rs, (float)tyv[it][e]);
           else t *= gelu_grad_dev((float)tyv[it][e]);
           v[e] = (bf16)t;
         }
@@ -1931,19 +1934,25 @@ int vc_conv_epilogue_side_supported(const int* desc, int dtype, int mode) {
   return dgrad_tail_eligible(g, dtype) ? 1 : 0;
 }
 
-// y = conv(x, w) + bias + residual, residual and y of the same [M][co] layout, written out of place (bf16).
-// Replaces the x + f(x) of the Swin blocks (timm SwinTransformerBlock behind model_components.py:254, 412).
+// y = row_scale * (conv(x, w) + bias) + residual, residual and y of the same [M][co] layout, written out of place
+// (bf16).  Replaces the x + drop_path(f(x)) of the Swin blocks (timm SwinTransformerBlock behind
+// model_components.py:254, 412).  row_scale (nullable = all ones): fp32, one value per rows_per_sample consecutive
+// rows (stochastic depth: 0 or 1 / keep probability per frame, from vc_drop_path_scales).
 int vc_conv_fwd_residual(const int* desc, int dtype, const void* x, const void* w_packed, const float* bias,
-                         const void* residual, void* y, hipStream_t stream) {
+                         const void* residual, const float* row_scale, int rows_per_sample, void* y,
+                         hipStream_t stream) {
   ConvGeom g;
   int rc = fill_geom(g, desc, 0, "vc_conv_fwd_residual");
   if (rc) return rc;
   VC_CHECK_ARG(x && w_packed && residual && y, "vc_conv_fwd_residual: null pointer");
   VC_CHECK_SHAPE(dgrad_tail_eligible(g, dtype),
                  "vc_conv_fwd_residual: unsupported geometry (ask vc_conv_epilogue_side_supported)");
+  VC_CHECK_SHAPE(!row_scale || (rows_per_sample > 0 && g.M % rows_per_sample == 0),
+                 "vc_conv_fwd_residual: %d rows do not split into samples of %d", g.M, rows_per_sample);
   const int tiles = ceil_div(g.M, BM) * ceil_div(g.Co, BN);
   const int grid = tiles < nt_persist_blocks() ? tiles : nt_persist_blocks();
-  launch_persist<0, 128, EPI_RESIDUAL>(g, grid, stream, x, w_packed, bias, y, 0, 0, 0, tiles, nullptr, residual, nullptr);
+  launch_persist<0, 128, EPI_RESIDUAL>(g, grid, stream, x, w_packed, bias, y, row_scale ? rows_per_sample : 0, 0, 0,
+                                       tiles, nullptr, residual, reinterpret_cast<const uint8_t*>(row_scale));
   VC_LAUNCH_CHECK("vc_conv_fwd_residual");
   return VC_OK;
 }

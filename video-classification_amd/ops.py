@@ -193,10 +193,20 @@ class _Conv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, kernel, stride, padding, relu, out_f32, ci, join, stats_groups, residual=None,
-                pre_gelu=False, want_gelu=False, gelu_x=None):
+                pre_gelu=False, want_gelu=False, gelu_x=None, drop=None):
         _require_cuda(x, "conv")
         ctx.join = join
         ctx.bn_pre = getattr(x, "_vc_bn_pre", None) if (join is None and FUSE_BN_PRE) else None
+        # drop = (p, samples): stochastic depth on this layer's result before the residual joins it; the rows split
+        # into `samples` equal contiguous samples.  Kept as (p, seed, samples): backward scales the gradient alike.
+        ctx.drop = None
+        drop_done = False
+        if drop is not None:
+            import ctypes
+            if residual is None:
+                raise RuntimeError("conv: stochastic depth is applied to a residual branch (residual missing)")
+            _dropout_seed[0] = (_dropout_seed[0] * 6364136223846793005 + 1442695040888963407) & 0x7FFFFFFFFFFFFFFF
+            ctx.drop = (float(drop[0]), ctypes.c_uint64(_dropout_seed[0]), int(drop[1]))
         # the slab-sum output never carries a gradient: do not let autograd fill a zero tensor of its size per call
         ctx.set_materialize_grads(False)
         x = x.contiguous()
@@ -265,14 +275,26 @@ class _Conv(torch.autograd.Function):
               tuple(residual.shape) == tuple(y.shape) and residual.dtype == y.dtype and
               L.query("vc_conv_epilogue_side_supported", L.int_array(desc), L.dtype_code(dtype), 0) == 1):
             res = residual.contiguous()
+            scales, rps = None, 0
+            if ctx.drop is not None:  # per-sample factors of the stochastic depth, applied to the rows in the epilogue
+                rps = M // ctx.drop[2]
+                scales = torch.empty(ctx.drop[2], device=x.device, dtype=torch.float32)
+                L.call("vc_drop_path_scales", L.ptr(scales), ctx.drop[2], ctx.drop[0], ctx.drop[1],
+                       L.ptr(seed_counter(x.device)), L.stream())
             _timed("conv_fwd", flops, lambda: L.call(
                 "vc_conv_fwd_residual", L.int_array(desc), L.dtype_code(dtype), L.ptr(x), L.ptr(wf), L.ptr(b),
-                L.ptr(res), L.ptr(y), L.stream()), nbytes + float(res.numel() * res.element_size()))
+                L.ptr(res), L.ptr(scales), rps, L.ptr(y), L.stream()), nbytes + float(res.numel() * res.element_size()))
             residual = None  # added
+            drop_done = True
         else:
             _timed("conv_fwd", flops, lambda: L.call(
                 "vc_conv_fwd", L.int_array(desc), L.dtype_code(dtype), L.ptr(x), 0, L.ptr(wf), L.ptr(b), L.ptr(y), 0,
                 int(relu), int(f32), 0, L.stream()), nbytes)
+        if ctx.drop is not None and not drop_done:  # outside the fused epilogue: a separate scaling pass
+            ys = torch.empty_like(y)
+            L.call("vc_drop_path", L.dtype_code(y.dtype), L.ptr(y), L.ptr(ys), L.i64(y.numel()),
+                   L.i64(y.numel() // ctx.drop[2]), ctx.drop[0], ctx.drop[1], L.ptr(seed_counter(x.device)), L.stream())
+            y = ys
         if residual is not None:  # geometry or dtype outside the fused epilogue: a separate add pass
             y = elementwise(0, y, cast(residual.contiguous().view(y.shape), y.dtype))
         ctx.flops = flops
@@ -296,6 +318,12 @@ class _Conv(torch.autograd.Function):
         dtype = x.dtype
         code = L.dtype_code(dtype)
         dy = cast(dy.contiguous(), dtype)
+        dres = dy if (len(ctx.needs_input_grad) > 11 and ctx.needs_input_grad[11]) else None
+        if ctx.drop is not None:  # the branch's gradient carries the sample factors, the residual's does not
+            dys = torch.empty_like(dy)
+            L.call("vc_drop_path", code, L.ptr(dy), L.ptr(dys), L.i64(dy.numel()), L.i64(dy.numel() // ctx.drop[2]),
+                   ctx.drop[0], ctx.drop[1], L.ptr(seed_counter(dy.device)), L.stream())
+            dy = dys
         if ctx.relu:
             dy = elementwise(1, dy, cast(y, dtype))
         desc = L.int_array(ctx.desc)
@@ -385,8 +413,7 @@ class _Conv(torch.autograd.Function):
         if side is not None:
             main.wait_stream(side)
         _ready(weight, bias)
-        dres = dy if (len(ctx.needs_input_grad) > 11 and ctx.needs_input_grad[11]) else None
-        grads = (dx, None, None, None, None, None, None, None, None, None, None, dres, None, None, None)
+        grads = (dx, None, None, None, None, None, None, None, None, None, None, dres, None, None, None, None)
         return grads[:len(ctx.needs_input_grad)]
 
 
@@ -590,19 +617,21 @@ def conv_bn(x, weight, bn, groups, bias=None, kernel=1, stride=1, padding=0, rel
 
 
 def linear(x, weight, bias=None, relu=False, out_f32=False, residual=None, pre_gelu=False, want_gelu=False,
-           gelu_x=None):
+           gelu_x=None, drop_path=0.0, samples=0):
     """x: [M, C] -> [M, pad8(Co)].  residual: [M, pad8(Co)] added to the result (in the GEMM's epilogue where the
     geometry allows).  pre_gelu: the layer is applied to gelu(x); the gradient through the GELU is then taken in the
     data-gradient GEMM's epilogue; gelu_x, if given, is gelu(x) as the producing layer wrote it.  want_gelu: returns
     (y, gelu(y)), the second from the same epilogue (None where the geometry does not allow it: the consumer then
-    computes it)."""
+    computes it).  drop_path > 0 (with residual): stochastic depth, the result is residual + f * (x W^T + b) with one
+    factor f in {0, 1 / (1 - drop_path)} per sample, the rows being `samples` equal contiguous samples."""
     M, C = x.shape
+    drop = (drop_path, samples) if (drop_path > 0.0 and residual is not None) else None
     if residual is None and not pre_gelu and not want_gelu:
         y = conv(x.view(M, 1, 1, 1, C), weight, bias, 1, 1, 0, relu, out_f32)
         return y.view(M, y.shape[-1])
     res = residual.view(M, 1, 1, 1, residual.shape[-1]) if residual is not None else None
     y, _, g = _Conv.apply(x.view(M, 1, 1, 1, C), weight, bias, 1, 1, 0, relu, out_f32, None, None, 0, res, pre_gelu,
-                          want_gelu, gelu_x)
+                          want_gelu, gelu_x, drop)
     y = y.view(M, y.shape[-1])
     if want_gelu:
         return y, (g.view(M, y.shape[-1]) if g.numel() else None)

@@ -51,20 +51,15 @@ class SwinBlock(nn.Module):
         qkv = ops.linear(y, self.attn.qkv.weight, self.attn.qkv.bias)
         a = ops.window_attention(qkv, self.attn.relative_position_bias_table, F_, H, W, self.attn.heads, self.ws,
                                  self.shift)
-        dropping = training and drop_path > 0.0
-        if dropping:  # a stochastic-depth branch is scaled per sample before it joins the residual stream
-            a = ops.linear(a, self.attn.proj.weight, self.attn.proj.bias)
-            t = ops.add(t, ops.drop_path(a, drop_path, training, F_))
-        else:         # x + proj(attn) in the projection GEMM's epilogue
-            t = ops.linear(a, self.attn.proj.weight, self.attn.proj.bias, residual=t)
+        # x + drop_path(proj(attn)) in the projection GEMM's epilogue: stochastic depth scales a frame's branch by one
+        # factor (0 or 1 / keep) before it joins the residual stream
+        dp = drop_path if training else 0.0
+        t = ops.linear(a, self.attn.proj.weight, self.attn.proj.bias, residual=t, drop_path=dp, samples=F_)
         t, y = ops.layer_norm_fork(t, self.norm2)
         h, gh = ops.linear(y, self.mlp.fc1.weight, self.mlp.fc1.bias, want_gelu=True)  # fc1 and gelu(fc1)
         # fc2 is applied to gelu(h); the gradient through the GELU is taken in fc2's data-gradient GEMM
-        if dropping:
-            y = ops.linear(h, self.mlp.fc2.weight, self.mlp.fc2.bias, pre_gelu=True, gelu_x=gh)
-            t = ops.add(t, ops.drop_path(y, drop_path, training, F_))
-        else:
-            t = ops.linear(h, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=t, pre_gelu=True, gelu_x=gh)
+        t = ops.linear(h, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=t, pre_gelu=True, gelu_x=gh, drop_path=dp,
+                       samples=F_)
         return t.view(F_, H, W, C)
 
 
@@ -102,7 +97,9 @@ class SwinT(nn.Module):
     """swin_tiny_patch4_window7_224 with num_classes=0: frames -> [F, 768] (final LayerNorm, mean over tokens)."""
 
     def __init__(self, img=224, patch=4, dim=96, depths=(2, 2, 6, 2), heads=(3, 6, 12, 24), ws=7,
-                 drop_path_rate=0.0):
+                 drop_path_rate=0.1):
+        # drop_path_rate: timm's SwinTransformer default, which timm.create_model(name, pretrained, num_classes=0)
+        # (model_components.py:254, 412) leaves in place: the reference trains with stochastic depth 0 .. 0.1
         super().__init__()
         self.patch_embed = PatchEmbed(dim, patch)
         res = img // patch
