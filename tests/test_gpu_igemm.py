@@ -392,3 +392,38 @@ def test_conv_dgrad_with_bn_pre(cuda, shape):
 
 
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(40, 24, 24, 25, 40), (70, 20, 24, 36, 72), (33, 50, 56, 144, 40)])
+@pytest.mark.parametrize("code", [0, 1])
+def test_many_tap_relayouts(cuda, shape, code):
+    """Layers with many taps (a Linear over a flattened feature map) take LDS-tiled transposing kernels for the forward
+    pack, the flat data-gradient pack and the gradient's way back: exact against torch permutes, padding included."""
+    from video_classification_amd import _lib as L
+    Co, Ci, Cip, taps, Cop = shape
+    dt = torch.float32 if code == 0 else torch.bfloat16
+    g = torch.Generator().manual_seed(9)
+    w = torch.randn(Co, Ci, taps, generator=g).to(cuda)
+    wf = torch.full((Co, taps, Cip), float("nan"), device=cuda, dtype=dt)
+    L.call("vc_pack_weight", code, L.ptr(w), L.ptr(wf), L.ptr(None), Co, Ci, taps, Cip, Cop, L.stream())
+    ref = torch.zeros(Co, taps, Cip, device=cuda)
+    ref[:, :, :Ci] = w.permute(0, 2, 1)
+    assert torch.equal(wf, ref.to(dt))
+    wt = torch.full((taps * Cip, Cop), float("nan"), device=cuda, dtype=dt)
+    L.call("vc_pack_weight_flat_t", code, L.ptr(w), L.ptr(wt), Co, Ci, taps, Cip, Cop, L.stream())
+    reft = torch.zeros(taps, Cip, Cop, device=cuda)
+    reft[:, :Ci, :Co] = w.permute(2, 1, 0)
+    assert torch.equal(wt.view(taps, Cip, Cop), reft.to(dt))
+    if code == 0:
+        dwp = torch.randn(Co, taps, Cip, generator=g).to(cuda)
+        keep = dwp.clone()
+        dw = torch.randn(Co, Ci, taps, generator=g).to(cuda)
+        base = dw.clone()
+        L.call("vc_unpack_wgrad", L.ptr(dwp), L.ptr(dw), Co, Ci, taps, Cip, 3, L.stream())
+        torch.cuda.synchronize()
+        assert torch.equal(dw, base + keep[:, :, :Ci].permute(0, 2, 1))
+        assert torch.count_nonzero(dwp[:, :, :Ci]) == 0      # cleared while read
+        L.call("vc_unpack_wgrad", L.ptr(keep), L.ptr(dw), Co, Ci, taps, Cip, 0, L.stream())
+        torch.cuda.synchronize()
+        assert torch.equal(dw, keep[:, :, :Ci].permute(0, 2, 1))

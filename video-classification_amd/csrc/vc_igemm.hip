@@ -1555,6 +1555,82 @@ __global__ void unpack_wgrad_kernel(float* __restrict__ dwp, float* __restrict__
   dw[idx] = (flags & 1) ? dw[idx] + v : v;
 }
 
+// ---- the same three re-layouts for layers with many taps (a Linear over a flattened feature map: 144 taps x 256
+// channels x 1024 outputs = 151 MB of fp32): 32 x 32 tiles through LDS, so that reads and writes both run along the
+// contiguous index of their side.  The element-wise forms above gather with a stride of `taps` floats. ----
+constexpr int TT = 32;
+// wf[co][t][c] = w[co][c][t] (zero for c >= Ci); grid (taps/32, Cip/32, Co)
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_tiled_kernel(const float* __restrict__ w, T* __restrict__ wf, int Ci,
+                                                                 int taps, int Cip) {
+  __shared__ float tile[TT][TT + 1];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int co = blockIdx.z, c0 = blockIdx.y * TT, t0 = blockIdx.x * TT;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, t = t0 + tx;
+    tile[ty + 8 * i][tx] = (c < Ci && t < taps) ? w[((size_t)co * Ci + c) * taps + t] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int t = t0 + ty + 8 * i, c = c0 + tx;
+    if (t < taps && c < Cip) wf[((size_t)co * taps + t) * Cip + c] = from_f32<T>(tile[tx][ty + 8 * i]);
+  }
+}
+
+// wt[(t * Cip + c)][co] = w[co][c][t] (zero for co >= Co, c >= Ci); grid (taps/32, Cop/32, Cip)
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_flat_t_tiled_kernel(const float* __restrict__ w, T* __restrict__ wt,
+                                                                        int Co, int Ci, int taps, int Cip, int Cop) {
+  __shared__ float tile[TT][TT + 1];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c = blockIdx.z, co0 = blockIdx.y * TT, t0 = blockIdx.x * TT;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int co = co0 + ty + 8 * i, t = t0 + tx;
+    tile[ty + 8 * i][tx] = (co < Co && c < Ci && t < taps) ? w[((size_t)co * Ci + c) * taps + t] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int t = t0 + ty + 8 * i, co = co0 + tx;
+    if (t < taps && co < Cop) wt[((size_t)t * Cip + c) * Cop + co] = from_f32<T>(tile[tx][ty + 8 * i]);
+  }
+}
+
+// dw[co][c][t] (+)= dwp[co][t][c]; flags as for unpack_wgrad_kernel; grid (taps/32, Ci/32, Co)
+__global__ __launch_bounds__(256) void unpack_wgrad_tiled_kernel(float* __restrict__ dwp, float* __restrict__ dw, int Ci,
+                                                                  int taps, int Cip, int flags) {
+  __shared__ float tile[TT][TT + 1];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int co = blockIdx.z, c0 = blockIdx.y * TT, t0 = blockIdx.x * TT;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int t = t0 + ty + 8 * i, c = c0 + tx;
+    float v = 0.f;
+    if (t < taps && c < Ci) {
+      const size_t src = ((size_t)co * taps + t) * Cip + c;
+      v = dwp[src];
+      if (flags & 2) dwp[src] = 0.f;
+    }
+    tile[ty + 8 * i][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, t = t0 + tx;
+    if (c < Ci && t < taps) {
+      const size_t dst = ((size_t)co * Ci + c) * taps + t;
+      const float v = tile[tx][ty + 8 * i];
+      dw[dst] = (flags & 1) ? dw[dst] + v : v;
+    }
+  }
+}
+
+// the tiled forms pay once a (channel, tap) plane is a few tiles large
+bool relayout_tiled(int co, int ci, int taps) { return taps >= 16 && ci >= 16 && co <= 65535 && ci <= 65535; }
+
 int fill_geom(ConvGeom& g, const int* d, int mode, const char* who) {
   // d: n, di, hi, wi, ci, do, ho, wo, co, kd, kh, kw, sd, sh, sw, pd, ph, pw  (forward meaning)
   const int n = d[0], di = d[1], hi = d[2], wi = d[3], ci = d[4], dout = d[5], ho = d[6], wo = d[7], co = d[8];
@@ -2091,6 +2167,16 @@ int vc_pack_weight(int dtype, const float* w, void* w_fwd, void* w_t, int co, in
   VC_CHECK_SHAPE(co > 0 && ci > 0 && taps > 0 && ci_pad >= ci && co_pad >= co, "vc_pack_weight: bad shape");
   const int64_t nf = w_fwd ? (int64_t)co * taps * ci_pad : 0, nt = w_t ? (int64_t)ci * taps * co_pad : 0;
   const int64_t total = nf > nt ? nf : nt;
+  if (w_fwd && !w_t && relayout_tiled(co, ci_pad, taps) && (dtype == VC_BF16 || dtype == VC_F32)) {
+    const dim3 grid(ceil_div(taps, TT), ceil_div(ci_pad, TT), co);
+    if (dtype == VC_BF16)
+      hipLaunchKernelGGL((pack_weight_tiled_kernel<bf16>), grid, dim3(256), 0, stream, w, (bf16*)w_fwd, ci, taps, ci_pad);
+    else
+      hipLaunchKernelGGL((pack_weight_tiled_kernel<float>), grid, dim3(256), 0, stream, w, (float*)w_fwd, ci, taps,
+                         ci_pad);
+    VC_LAUNCH_CHECK("vc_pack_weight");
+    return VC_OK;
+  }
   if (dtype == VC_BF16)
     hipLaunchKernelGGL((pack_weight_kernel<bf16>), dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, stream, w,
                        (bf16*)w_fwd, (bf16*)w_t, co, ci, taps, ci_pad, co_pad);
@@ -2110,6 +2196,17 @@ int vc_pack_weight_flat_t(int dtype, const float* w, void* w_t, int co, int ci, 
   VC_CHECK_ARG(w && w_t, "vc_pack_weight_flat_t: null pointer");
   VC_CHECK_SHAPE(co > 0 && ci > 0 && taps > 0 && ci_pad >= ci && co_pad >= co, "vc_pack_weight_flat_t: bad shape");
   const int64_t total = (int64_t)taps * ci_pad * co_pad;
+  if (relayout_tiled(ci_pad, co_pad, taps) && (dtype == VC_BF16 || dtype == VC_F32)) {
+    const dim3 grid(ceil_div(taps, TT), ceil_div(co_pad, TT), ci_pad);
+    if (dtype == VC_BF16)
+      hipLaunchKernelGGL((pack_weight_flat_t_tiled_kernel<bf16>), grid, dim3(256), 0, stream, w, (bf16*)w_t, co, ci, taps,
+                         ci_pad, co_pad);
+    else
+      hipLaunchKernelGGL((pack_weight_flat_t_tiled_kernel<float>), grid, dim3(256), 0, stream, w, (float*)w_t, co, ci,
+                         taps, ci_pad, co_pad);
+    VC_LAUNCH_CHECK("vc_pack_weight_flat_t");
+    return VC_OK;
+  }
   if (dtype == VC_BF16)
     hipLaunchKernelGGL((pack_weight_flat_t_kernel<bf16>), dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, stream,
                        w, (bf16*)w_t, co, ci, taps, ci_pad, co_pad);
@@ -2158,6 +2255,12 @@ int vc_unpack_wgrad(float* dw_packed, float* dw, int co, int ci, int taps, int c
                     hipStream_t stream) {
   VC_CHECK_ARG(dw_packed && dw, "vc_unpack_wgrad: null pointer");
   const int64_t total = (int64_t)co * ci * taps;
+  if (relayout_tiled(co, ci, taps)) {
+    hipLaunchKernelGGL(unpack_wgrad_tiled_kernel, dim3(ceil_div(taps, TT), ceil_div(ci, TT), co), dim3(256), 0, stream,
+                       dw_packed, dw, ci, taps, ci_pad, flags);
+    VC_LAUNCH_CHECK("vc_unpack_wgrad");
+    return VC_OK;
+  }
   hipLaunchKernelGGL(unpack_wgrad_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, stream, dw_packed, dw,
                      co, ci, taps, ci_pad, flags);
   VC_LAUNCH_CHECK("vc_unpack_wgrad");

@@ -150,18 +150,19 @@ def _triple(v):
     return tuple(v) if isinstance(v, (tuple, list)) else (v, v, v)
 
 
-def _packed_weights(weight, ci, taps, cip, cop, dtype):
-    """(forward pack [cop][taps][cip], transposed pack [Ci][taps][cop]) in the compute dtype."""
+def _packed_weights(weight, ci, taps, cip, cop, dtype, want_t=True):
+    """(forward pack [cop][taps][cip], transposed pack [Ci][taps][cop]) in the compute dtype; want_t=False: the
+    second is None (a layer that brings its own data-gradient pack)."""
     # The pack is cached on the parameter object itself (it dies with it) and is valid while neither
     # autograd's version counter nor the library's own "weights rewritten" epoch has moved.
-    key = (weight.data_ptr(), weight._version, _weights_epoch, dtype, cip, cop, taps)
+    key = (weight.data_ptr(), weight._version, _weights_epoch, dtype, cip, cop, taps, want_t)
     cache = getattr(weight, "_vc_pack", None)
     if cache is not None and cache[0] == key:
         return cache[1], cache[2]
     co = weight.shape[0]
     # the pack kernel writes every element of the first co rows; only padded output rows need the zero fill
     wf = (torch.empty if cop == co else torch.zeros)(cop, taps, cip, device=weight.device, dtype=dtype)
-    wt = torch.empty(ci, taps, cop, device=weight.device, dtype=dtype)
+    wt = torch.empty(ci, taps, cop, device=weight.device, dtype=dtype) if want_t else None
     w = weight.detach().contiguous()
     L.call("vc_pack_weight", L.dtype_code(dtype), L.ptr(w), L.ptr(wf), L.ptr(wt), co, ci, taps, cip, cop, L.stream())
     weight._vc_pack = (key, wf, wt)
@@ -231,8 +232,9 @@ class _Conv(torch.autograd.Function):
         desc = [N, D, H, W, cip, Do, Ho, Wo, cop, *k, *s, *p]
         if weight.numel() != co * ci * taps:
             raise RuntimeError(f"conv: weight of shape {tuple(weight.shape)} is not [Co={co}, Ci={ci}, taps={taps}]")
-        wf, wt = _packed_weights(weight, ci, taps, cip, cop, dtype)
-        if taps > 1 and (Do, Ho, Wo) == (1, 1, 1) and p == (0, 0, 0) and k == (D, H, W):
+        flat = taps > 1 and (Do, Ho, Wo) == (1, 1, 1) and p == (0, 0, 0) and k == (D, H, W)
+        wf, wt = _packed_weights(weight, ci, taps, cip, cop, dtype, want_t=not flat)
+        if flat:
             # the kernel covers the whole input: a Linear layer over the flattened channels-last map.  Same
             # forward pack; the data gradient uses a tap-major transposed pack (every tap is valid for exactly
             # one input pixel, so the gather form would waste taps-1 of every taps products).
