@@ -55,6 +55,13 @@ int vc_conv_fwd(const int* desc, int dtype, const void* x, int ldx, const void* 
 int vc_conv_fwd_stats_supported(const int* desc, int dtype, int ldx, int out_f32);
 int vc_conv_fwd_stats(const int* desc, int dtype, const void* x, int ldx, const void* w_packed, const float* bias,
                       void* y, int ldy, int relu, float* bn_partial, vc_stream_t stream);
+/* Forward layer whose reduction is cut into slices: few output tiles and a long reduction (EncoderCNN.fc1,
+ * model_components.py:104 / :131: 36864 -> fc_hidden1 on B*T rows) would otherwise occupy a fraction of the chip.
+ * vc_conv_fwd_splitk_plan returns the number of slices (1 = not split: use vc_conv_fwd); vc_conv_fwd_splitk needs
+ * workspace [slices][M][co] fp32 and writes y = act(conv(x) + bias) as bf16 (fp32 with out_f32). */
+int vc_conv_fwd_splitk_plan(const int* desc, int dtype);
+int vc_conv_fwd_splitk(const int* desc, int dtype, const void* x, const void* w_packed, const float* bias, void* y,
+                       int relu, int out_f32, float* workspace, vc_stream_t stream);
 int vc_conv_dgrad(const int* desc, int dtype, const void* dy, int lddy, const void* w_packed_t, void* dx, int lddx,
                   int out_f32, int beta, vc_stream_t stream);
 /* vc_conv_dgrad (bf16, stride 1, dense rows, beta as above) for the LAST contribution to the gradient of a residual

@@ -427,3 +427,30 @@ def test_many_tap_relayouts(cuda, shape, code):
         L.call("vc_unpack_wgrad", L.ptr(keep), L.ptr(dw), Co, Ci, taps, Cip, 0, L.stream())
         torch.cuda.synchronize()
         assert torch.equal(dw, keep[:, :, :Ci].permute(0, 2, 1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(300, 2048, 192, 2), (512, 8192, 256, 8), (130, 36864, 1024, 32), (512, 36864, 1024, 16)])
+def test_forward_with_split_reduction(cuda, shape):
+    """vc_conv_fwd_splitk (few output tiles, long reduction: (tile, slice) work units + a pass that adds the slices)
+    against vc_conv_fwd: fp32 results agree to summation order, bf16 results with bias and ReLU to one rounding."""
+    from video_classification_amd import _lib as L
+    M, K, N, S = shape
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(M, K, generator=g).to(cuda, torch.bfloat16)
+    wf = (torch.randn(N, 1, K, generator=g) * 0.02).to(cuda, torch.bfloat16)
+    bias = torch.randn(N, generator=g).to(cuda)
+    desc = L.int_array([M, 1, 1, 1, K, 1, 1, 1, N, 1, 1, 1, 1, 1, 1, 0, 0, 0])
+    assert L.query("vc_conv_fwd_splitk_plan", desc, 1) == S
+    assert L.query("vc_conv_fwd_splitk_plan", L.int_array([100000, 1, 1, 1, K, 1, 1, 1, N, 1, 1, 1, 1, 1, 1, 0, 0, 0]), 1) == 1
+    ws = torch.full((S, M, N), float("nan"), device=cuda)
+    for relu, f32 in ((0, 1), (1, 0)):
+        dt = torch.float32 if f32 else torch.bfloat16
+        y0 = torch.empty(M, N, device=cuda, dtype=dt)
+        y1 = torch.empty(M, N, device=cuda, dtype=dt)
+        L.call("vc_conv_fwd", desc, 1, L.ptr(x), 0, L.ptr(wf), L.ptr(bias), L.ptr(y0), 0, relu, f32, 0, L.stream())
+        L.call("vc_conv_fwd_splitk", desc, 1, L.ptr(x), L.ptr(wf), L.ptr(bias), L.ptr(y1), relu, f32, L.ptr(ws),
+               L.stream())
+        torch.cuda.synchronize()
+        assert not torch.isnan(ws).any()
+        assert _rel(y1.float().cpu(), y0.float().cpu()) < (1e-5 if f32 else 8e-3)  # bf16: one ulp at the top

@@ -180,4 +180,7 @@ struct ConvGeom {
   int wt_h0, wt_hs, wt_w0, wt_ws;  // weight tap rh = wt_h0 + wt_hs*ah, rw = wt_w0 + wt_ws*aw
   int oHo, oWo;                    // extent of the image the output rows live in
   int o_h0, o_hs, o_w0, o_ws;      // output pixel h = o_h0 + o_hs*hc, w = o_w0 + o_ws*wc
+  // Split reduction of a single-tap layer (persistent NT kernel): work unit v = tile * ksplit + slice; a slice
+  // covers 1 / ksplit of the channels and writes its own fp32 partial [slice][M][ldc].  1 = whole reduction.
+  int ksplit;
 };

@@ -763,10 +763,14 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
   const int lchunk = pchunk ^ ((lrow >> 1) & 7);
   // k-tiles per tap; a single-tap layer (linear, 1x1 convolution) may have any channel count that is a
   // multiple of 8: the chunks of its last k-tile that lie beyond Ci read zeros
-  const int ncb = (g.Ci + BK - 1) / BK;
-  const int nk = g.kd * g.kh * g.kw * ncb;  // k-tiles per output tile (>= 1)
+  const int KS = g.ksplit;                       // > 1: single tap, Ci % (BK * KS) == 0, fp32 partial outputs
+  const int ncb = (g.Ci + BK - 1) / BK / KS;     // k-tiles per tap (and slice)
+  const int nk = g.kd * g.kh * g.kw * ncb;       // k-tiles per work unit (>= 1)
   const bool ktail = (g.Ci % BK) != 0;
   const bf16* zero = reinterpret_cast<const bf16*>(vc_zero_src);
+  // work unit -> output tile and the element offset of its slice inside a source / weight row
+  auto unit_tile = [&](int v) { return KS > 1 ? v / KS : v; };
+  auto unit_koff = [&](int v) { return KS > 1 ? (v - (v / KS) * KS) * ncb * BK : 0; };
 
   // A staging cursor: which k-tile of which output tile comes next.  The source rows and the weight rows have one
   // each (the source runs further ahead); both are wave-uniform.
@@ -801,16 +805,17 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
 
   auto stage_a_gl = [&](bf16* sA, KCursor& c) {
     if (c.kt == 0) {  // first k-tile of an output tile: its rows
-      const int m0 = (c.tile / tiles_n) * BM;
+      const int m0 = (unit_tile(c.tile) / tiles_n) * BM;
 #pragma unroll
       for (int i = 0; i < 4; ++i) rp[i] = decode_row<MODE>(g, m0 + lrow + 32 * i);
     }
     if (c.cb == 0) {
+      const int koff = unit_koff(c.tile);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int pix = gather_pixel<MODE>(g, rp[i], c.rd, c.rh, c.rw);
         const bool ok = pix >= 0;
-        ap[i] = ok ? src + (size_t)pix * g.ldi + lchunk * 8 : zero;
+        ap[i] = ok ? src + (size_t)pix * g.ldi + lchunk * 8 + koff : zero;
         ainc[i] = ok ? BK : 0;
       }
     }
@@ -822,13 +827,15 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
     advance(c);
   };
   auto stage_w_gl = [&](bf16* sW, KCursor& c) {
-    const int tile_m = c.tile / tiles_n, n0 = (c.tile - tile_m * tiles_n) * TN_;
+    const int rt = unit_tile(c.tile);
+    const int tile_m = rt / tiles_n, n0 = (rt - tile_m * tiles_n) * TN_;
     if (c.kt == 0) {
+      const int koff = unit_koff(c.tile);
 #pragma unroll
       for (int i = 0; i < NWROW; ++i) {
         const int co = n0 + lrow + 32 * i;
         const bool ok = co < g.Co;
-        wp[i] = ok ? wgt + (size_t)co * g.ldw + lchunk * 8 : zero;
+        wp[i] = ok ? wgt + (size_t)co * g.ldw + lchunk * 8 + koff : zero;
         winc[i] = ok ? BK : 0;
       }
     }
@@ -950,8 +957,12 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
   int c_tile = vblock, c_kt = 0;
   auto finish_ktile = [&](bf16* tA, bf16* tW) {
     if (++c_kt == nk) {  // output tile complete
-      const int tile_m = c_tile / tiles_n, tile_n = c_tile - tile_m * tiles_n;
-      if (out_f32) {
+      const int rt = unit_tile(c_tile);
+      const int tile_m = rt / tiles_n, tile_n = rt - tile_m * tiles_n;
+      if (KS > 1) {  // this slice's fp32 partial; bias and activation belong to the pass that adds the slices
+        float* part = reinterpret_cast<float*>(out) + (size_t)(c_tile - rt * KS) * g.M * g.ldc;
+        nt_epilogue<MODE, WI>(g, acc, tile_m * BM, tile_n * TN_, wm, wn, lane, nullptr, part, 0, 1, 0);
+      } else if (out_f32) {
         nt_epilogue<MODE, WI>(g, acc, tile_m * BM, tile_n * TN_, wm, wn, lane, bias, out, relu, out_f32, beta);
       } else {
         // the k-tile that was just multiplied is free once every wave has finished reading it (LDS reads only:
@@ -1628,6 +1639,31 @@ __global__ __launch_bounds__(256) void unpack_wgrad_tiled_kernel(float* __restri
   }
 }
 
+// y[m][c] = act(sum_s partial[s][m][c] + bias[c]): the pass that adds the slices of a split reduction
+template <typename T>
+__global__ void splitk_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
+                                     T* __restrict__ y, int64_t n4, int C4, int S, int64_t slice, int relu) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(partial + i * 4);
+    for (int s2 = 1; s2 < S; ++s2) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(partial + s2 * slice + i * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a[r] += b[r];
+    }
+    if (bias) {
+      const int c = (int)(i % C4) * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a[r] += bias[c + r];
+    }
+    if (relu) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a[r] = fmaxf(a[r], 0.f);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y[i * 4 + r] = from_f32<T>(a[r]);
+  }
+}
+
 // the tiled forms pay once a (channel, tap) plane is a few tiles large
 bool relayout_tiled(int co, int ci, int taps) { return taps >= 16 && ci >= 16 && co <= 65535 && ci <= 65535; }
 
@@ -1644,6 +1680,7 @@ int fill_geom(ConvGeom& g, const int* d, int mode, const char* who) {
                  "%s: output extent does not match input/kernel/stride/pad", who);
   VC_CHECK_SHAPE((int64_t)n * di * hi * wi * ci < (1ll << 31) && (int64_t)n * dout * ho * wo * co < (1ll << 31),
                  "%s: tensor exceeds 2^31 elements", who);
+  g.ksplit = 1;
   g.kd = kd; g.kh = kh; g.kw = kw;
   g.sd = sd; g.sh = sh; g.sw = sw;
   g.pd = pd; g.ph = ph; g.pw = pw;
@@ -1752,6 +1789,20 @@ bool nt_persist_eligible(const ConvGeom& g, int dtype) {
          (g.Ci % BK == 0 || (single_tap && g.Ci % 8 == 0));
 }
 
+// Slices a single-tap layer's reduction should be cut into so that a launch fills the chip (1 = leave it whole):
+// few output tiles, a long reduction (CRNN's fc1: 4 x 8 tiles of 128 x 128, 36864 channels -> 16 slices of 36 k-tiles)
+int ksplit_plan(const ConvGeom& g, int dtype) {
+  if (!nt_persist_eligible(g, dtype) || g.kd * g.kh * g.kw != 1 || g.Ci % BK || g.Co % 4 || g.ldc != g.Co ||
+      g.Co <= nt_narrow())
+    return 1;
+  const int tiles = ceil_div(g.M, BM) * ceil_div(g.Co, BN);
+  const int ncb = g.Ci / BK;
+  int S = 1;
+  // two work units per CU as for whole layers; more slices only add partial-sum traffic
+  while (S < 32 && tiles * S < 512 && ncb % (S * 2) == 0 && ncb / (S * 2) >= 16) S *= 2;
+  return tiles <= 128 ? S : 1;
+}
+
 // VC_IGEMM_BL=0 keeps the global-load staging of the persistent kernel everywhere, 2 uses the buffer form for
 // single-tap layers too (A/B measurements); default 1 = buffer form for multi-tap convolutions
 int use_bl() {
@@ -1792,7 +1843,7 @@ void launch_persist(const ConvGeom& g, int grid, hipStream_t stream, const void*
   hipLaunchKernelGGL((igemm_nt_persist_kernel<MODE, TN, EPI, BL_, NA_>), dim3(grid), dim3(NTHR), 0, stream, g,       \
                      (const bf16*)src, (const bf16*)wgt, bias, out, relu, out_f32, beta, ntiles, bn_partial,         \
                      (const bf16*)tail_y, tail_bits)
-  const bool bl = bl_eligible(g, MODE);
+  const bool bl = bl_eligible(g, MODE) && g.ksplit == 1;
   // Three staged source k-tiles pay where the source streams from HBM into wide tiles: measured on the ResNet-50 layer
   // table, 1x1 layers of 256..1024 channels at 28 x 28 and 14 x 14 gain 5-12 % (forward and data gradient); the
   // 64-channel tile loses a third (64 KiB of LDS: two blocks per CU instead of three), multi-tap layers lose 5 % (their
@@ -1877,6 +1928,41 @@ int vc_conv_fwd(const int* desc, int dtype, const void* x, int ldx, const void* 
   VC_CHECK_SHAPE(g.ldc >= g.Co && g.ldi >= g.Ci, "vc_conv_fwd: leading dimension smaller than channel count");
   VC_CHECK_SHAPE(dtype != VC_BF16 || g.ldi % 8 == 0, "vc_conv_fwd: bf16 path needs ldx %% 8 == 0");
   return launch_nt<0>(g, dtype, x, w_packed, bias, y, relu, out_f32, beta, stream, "vc_conv_fwd");
+}
+
+// Forward layer with its reduction cut into slices (vc_conv_fwd_splitk_plan(desc, dtype) > 1 of them; 1 = use
+// vc_conv_fwd): one launch computes every (output tile, slice) pair into workspace [slices][M][co] fp32, a second
+// adds the slices, the bias and the ReLU into y (bf16, or fp32 with out_f32).
+int vc_conv_fwd_splitk_plan(const int* desc, int dtype) {
+  ConvGeom g;
+  if (fill_geom(g, desc, 0, "vc_conv_fwd_splitk_plan")) return 1;
+  return ksplit_plan(g, dtype);
+}
+
+int vc_conv_fwd_splitk(const int* desc, int dtype, const void* x, const void* w_packed, const float* bias, void* y,
+                       int relu, int out_f32, float* workspace, hipStream_t stream) {
+  ConvGeom g;
+  int rc = fill_geom(g, desc, 0, "vc_conv_fwd_splitk");
+  if (rc) return rc;
+  VC_CHECK_ARG(x && w_packed && y && workspace, "vc_conv_fwd_splitk: null pointer");
+  const int S = ksplit_plan(g, dtype);
+  VC_CHECK_SHAPE(S > 1, "vc_conv_fwd_splitk: this geometry is not split (ask vc_conv_fwd_splitk_plan)");
+  g.ksplit = S;
+  const int units = ceil_div(g.M, BM) * ceil_div(g.Co, BN) * S;
+  const int grid = units < nt_persist_blocks() ? units : nt_persist_blocks();
+  launch_persist<0, 128, EPI_NONE>(g, grid, stream, x, w_packed, nullptr, workspace, 0, 1, 0, units, nullptr, nullptr,
+                                   nullptr);
+  VC_LAUNCH_CHECK("vc_conv_fwd_splitk");
+  const int64_t n4 = (int64_t)g.M * g.Co / 4;
+  const unsigned rgrid = (unsigned)(ceil_div64(n4, 256) < 4096 ? ceil_div64(n4, 256) : 4096);
+  if (out_f32)
+    hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(rgrid), dim3(256), 0, stream, workspace, bias, (float*)y, n4,
+                       g.Co / 4, S, (int64_t)g.M * g.Co, relu);
+  else
+    hipLaunchKernelGGL((splitk_reduce_kernel<bf16>), dim3(rgrid), dim3(256), 0, stream, workspace, bias, (bf16*)y, n4,
+                       g.Co / 4, S, (int64_t)g.M * g.Co, relu);
+  VC_LAUNCH_CHECK("vc_conv_fwd_splitk");
+  return VC_OK;
 }
 
 int vc_conv_fwd_stats_supported(const int* desc, int dtype, int ldx, int out_f32) {

@@ -288,6 +288,13 @@ class _Conv(torch.autograd.Function):
                 L.ptr(res), L.ptr(scales), rps, L.ptr(y), L.stream()), nbytes + float(res.numel() * res.element_size()))
             residual = None  # added
             drop_done = True
+        elif SPLIT_K and L.query("vc_conv_fwd_splitk_plan", L.int_array(desc), L.dtype_code(dtype)) > 1:
+            # few output tiles, long reduction: (tile, slice) work units fill the chip, a second pass adds the slices
+            ns = L.query("vc_conv_fwd_splitk_plan", L.int_array(desc), L.dtype_code(dtype))
+            ws = torch.empty(ns, M, cop, device=x.device, dtype=torch.float32)
+            _timed("conv_fwd", flops, lambda: L.call(
+                "vc_conv_fwd_splitk", L.int_array(desc), L.dtype_code(dtype), L.ptr(x), L.ptr(wf), L.ptr(b), L.ptr(y),
+                int(relu), int(f32), L.ptr(ws), L.stream()), nbytes)
         else:
             _timed("conv_fwd", flops, lambda: L.call(
                 "vc_conv_fwd", L.int_array(desc), L.dtype_code(dtype), L.ptr(x), 0, L.ptr(wf), L.ptr(b), L.ptr(y), 0,
@@ -435,6 +442,8 @@ def _side_stream(device):
 
 # VC_FUSE_EPILOGUE=0 keeps residual adds and the GELU gradient in their own elementwise passes (A/B measurements)
 FUSE_EPILOGUE_SIDE = os.environ.get("VC_FUSE_EPILOGUE", "1") != "0"
+# VC_SPLIT_K=0 keeps every forward layer's reduction whole (A/B measurements)
+SPLIT_K = os.environ.get("VC_SPLIT_K", "1") != "0"
 # VC_FUSE_BN_STATS=0 keeps BatchNorm statistics in their own pass over y (A/B measurements)
 FUSE_BN_STATS = os.environ.get("VC_FUSE_BN_STATS", "1") != "0"
 
