@@ -597,6 +597,100 @@ class SwinTCGModel(_EncDec):
     pass
 
 
+# ----------------------------------------------------------------------------------------------
+# Image / density fusion CNN (models/swintransformer_RNN/image_density_fusion.py)
+# ----------------------------------------------------------------------------------------------
+class ChannelAttention(nn.Module):
+    """image_density_fusion.py:14-34: sigmoid(mlp(avgpool(x)) + mlp(maxpool(x))), mlp = 1x1 conv C -> C/r -> C."""
+
+    def __init__(self, channels, reduction=16):
+        super().__init__()
+        self.fc = nn.Sequential(nn.Conv2d(channels, channels // reduction, 1, bias=False), nn.ReLU(inplace=True),
+                                nn.Conv2d(channels // reduction, channels, 1, bias=False))
+
+    def forward(self, x):  # [N, C, H, W] -> [N, C, 1, 1]
+        return torch.sigmoid(self.fc(x.mean((2, 3), keepdim=True)) + self.fc(x.amax((2, 3), keepdim=True)))
+
+
+class SpatialAttention(nn.Module):
+    """image_density_fusion.py:37-51: sigmoid(conv7x7([mean over C, max over C]))."""
+
+    def __init__(self, kernel_size=7):
+        super().__init__()
+        self.conv = nn.Conv2d(2, 1, kernel_size, padding=kernel_size // 2, bias=False)
+
+    def forward(self, x):  # [N, C, H, W] -> [N, 1, H, W]
+        return torch.sigmoid(self.conv(torch.cat([x.mean(1, keepdim=True), x.amax(1, keepdim=True)], 1)))
+
+
+class LocalFeatureExtraction(nn.Module):
+    """image_density_fusion.py:54-87."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, padding=1)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
+        self.bn2 = nn.BatchNorm2d(cout)
+        self.channel_attention = ChannelAttention(cout)
+        self.spatial_attention = SpatialAttention()
+
+    def forward(self, x):
+        y = _r(F.relu(self.bn1(_conv(self.conv1, x))))
+        y = _r(self.bn2(_conv(self.conv2, y)))
+        y = y * self.channel_attention(y)       # (the device applies both gates and the ReLU in one pass, fp32)
+        return _r(F.relu(y * self.spatial_attention(y)))
+
+
+class MultiScaleFeatureAggregation(nn.Module):
+    """image_density_fusion.py:90-128: 1x1 / 3x3 / 5x5 / 7x7 branches of cout/4 channels, concatenated."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv1x1 = nn.Conv2d(cin, cout // 4, 1)
+        self.conv3x3 = nn.Conv2d(cin, cout // 4, 3, padding=1)
+        self.conv5x5 = nn.Conv2d(cin, cout // 4, 5, padding=2)
+        self.conv7x7 = nn.Conv2d(cin, cout // 4, 7, padding=3)
+        self.bn = nn.BatchNorm2d(cout)
+        self.fusion_conv = nn.Conv2d(cout, cout, 1)
+        self.fusion_bn = nn.BatchNorm2d(cout)
+
+    def forward(self, x):
+        y = torch.cat([_conv(m, x) for m in (self.conv1x1, self.conv3x3, self.conv5x5, self.conv7x7)], 1)
+        y = _r(F.relu(self.bn(y)))
+        return _r(F.relu(self.fusion_bn(_conv(self.fusion_conv, y))))
+
+
+class ImageDensityFusion(nn.Module):
+    """image_density_fusion.py:131-257: [image, density map] -> conv-bn-relu -> LocalFeatureExtraction ->
+    MultiScaleFeatureAggregation -> 1x1 conv-bn-relu -> global average pool."""
+
+    def __init__(self, input_channels=3, density_channels=1, feature_channels=64, output_channels=512):
+        super().__init__()
+        fc = feature_channels
+        self.initial_conv = nn.Sequential(nn.Conv2d(input_channels + density_channels, fc, 3, padding=1),
+                                          nn.BatchNorm2d(fc), nn.ReLU(inplace=True))
+        self.local_feature_extraction = LocalFeatureExtraction(fc, fc)
+        self.multi_scale_aggregation = MultiScaleFeatureAggregation(fc, 2 * fc)
+        self.final_conv = nn.Sequential(nn.Conv2d(2 * fc, output_channels, 1), nn.BatchNorm2d(output_channels),
+                                        nn.ReLU(inplace=True), nn.AdaptiveAvgPool2d((1, 1)))
+        self.output_dim = output_channels
+
+    def forward(self, original_image, density_channel):  # [N,C,H,W], [N,1,h,w] -> [N, output_channels]
+        if original_image.shape[-2:] != density_channel.shape[-2:]:
+            density_channel = F.interpolate(density_channel, size=original_image.shape[-2:], mode="bilinear",
+                                            align_corners=False)
+        x = _r(torch.cat([original_image, density_channel], 1))
+        x = _r(F.relu(self.initial_conv[1](_conv(self.initial_conv[0], x))))
+        x = self.multi_scale_aggregation(self.local_feature_extraction(x))
+        x = _r(F.relu(self.final_conv[1](_conv(self.final_conv[0], x))))
+        return x.mean((2, 3))
+
+    def forward_batch(self, video_frames, density_channels):  # [B,T,C,H,W], [B,T,1,h,w] -> [B, T, output_channels]
+        B, T = video_frames.shape[:2]
+        return self.forward(video_frames.flatten(0, 1), density_channels.flatten(0, 1)).view(B, T, -1)
+
+
 def train_step(model, data, target, criterion, optimizer):
     """One batch of train_epoch (training_utils.py:73-92): returns (loss, logits, n_correct)."""
     model.train()

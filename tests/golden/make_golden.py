@@ -136,6 +136,38 @@ def main():
         d.update({"loss_wg": wg.numpy(), "loss_wc": wc.numpy(), "out_g": gg.detach().numpy(), "out_c": cc.detach().numpy()})
         d.update(_grads(enc))
         _save("cluster_swin_standin", d)
+    if not only or "image_density_fusion" in only:
+        # 10. ImageDensityFusion (models/swintransformer_RNN/image_density_fusion.py:131): channel / spatial attention
+        #     block, the four-branch multi-scale block and the pooled 1x1 head.  The file imports cv2 (absent here) at
+        #     module level without using it in these classes: an empty stub module stands in for it.
+        if "cv2" not in sys.modules:
+            sys.modules["cv2"] = types.ModuleType("cv2")
+        spec = importlib.util.spec_from_file_location(
+            "ref_idf", os.path.join(REF, "models/swintransformer_RNN/image_density_fusion.py"))
+        idf = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(idf)
+        torch.manual_seed(0)
+        m = idf.create_image_density_fusion(input_channels=3, density_channels=1, feature_channels=32, output_channels=64)
+        with torch.no_grad():  # non-trivial BatchNorm affines, as after training
+            for n, p in m.named_parameters():
+                if p.dim() == 1:
+                    p.add_(0.1 * torch.randn(p.shape, generator=g.manual_seed(zlib.crc32(n.encode()) % 1000)))
+        _component_case("image_density_fusion", m, {"img": torch.randn(4, 3, 16, 16, generator=g.manual_seed(21)),
+                                                    "den": torch.rand(4, 1, 16, 16, generator=g.manual_seed(22))})
+        # the density map at another resolution (bilinear resize inside forward) and the [B, T] wrapper
+        torch.manual_seed(0)
+        m = idf.create_image_density_fusion(input_channels=3, density_channels=1, feature_channels=32, output_channels=64)
+        x = torch.randn(2, 2, 3, 16, 16, generator=g.manual_seed(23))
+        den = torch.rand(2, 2, 1, 8, 8, generator=g.manual_seed(24))
+        d = {"in/x": x.numpy(), "in/den": den.numpy()}
+        d.update(_sd("p", m))
+        m.train()
+        out = m.forward_batch(x, den)
+        w = torch.randn(out.shape, generator=g.manual_seed(25))
+        (out * w).sum().backward()
+        d.update({"loss_w": w.numpy(), "out_train": out.detach().numpy()})
+        d.update(_grads(m))
+        _save("image_density_fusion_batch", d)
     if only:
         return
 

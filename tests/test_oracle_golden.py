@@ -127,3 +127,20 @@ def test_crnn_full_config0():
         assert abs(p.grad.double().norm().item() - ref) <= 1e-4 * ref + 1e-12, k
     assert G.max_rel(model.decoder.fc2.weight.grad, d["g/decoder.fc2.weight"]) < 5 * TOL
     assert G.max_rel(model.encoder.conv1[0].weight.grad, d["g/encoder.conv1.0.weight"]) < 5 * TOL
+
+
+def test_image_density_fusion():
+    """The fusion CNN against the reference's own class (models/swintransformer_RNN/image_density_fusion.py:131)."""
+    _run_component("image_density_fusion", O.ImageDensityFusion(3, 1, 32, 64), ["img", "den"])
+
+
+def test_image_density_fusion_batch_and_resized_density():
+    d = G.load("image_density_fusion_batch")
+    m = O.ImageDensityFusion(3, 1, 32, 64)
+    m.load_state_dict(G.group(d, "p"), strict=True)
+    m.train()
+    out = m.forward_batch(torch.from_numpy(d["in/x"]), torch.from_numpy(d["in/den"]))
+    (out * torch.from_numpy(d["loss_w"])).sum().backward()
+    assert G.max_rel(out.detach(), d["out_train"]) < 1e-5
+    for k, p in m.named_parameters():
+        assert G.max_rel(p.grad, d[f"g/{k}"]) < 1e-4, k
