@@ -230,6 +230,24 @@ int vc_drop_path(int dtype, const void* x, void* out, int64_t n, int64_t elems_p
 int vc_drop_path_scales(float* scales, int samples, float p, uint64_t seed, const int64_t* seed_dev,
                         vc_stream_t stream);
 
+/* ---- Channel + spatial attention gate of the image / density fusion CNN
+ * (models/swintransformer_RNN/image_density_fusion.py:14-87: ChannelAttention, SpatialAttention and their use in
+ * LocalFeatureExtraction.forward :80-86).  x, out, dout, dx: channels-last [N][H*W][C] in `dtype`;
+ * W1 [C/r][C], W2 [C][C/r] (ChannelAttention.fc.0 / fc.2), Ws [1][2][k][k] (SpatialAttention.conv), all fp32.
+ * out = relu(y * sigmoid(conv(mean_c y, max_c y))), y = x * sigmoid(mlp(avg_p x) + mlp(max_p x)).  The forward call
+ * writes what backward needs into caller-allocated fp32 / int32 buffers: avg, mx, gc [N][C]; argp [N][C]; hid
+ * [N][2][C/r]; pooled [N][H*W][2]; argc, gs [N][H*W]; workspace: vc_cbam_workspace_floats() floats.  Backward
+ * writes dx and ACCUMULATES dW1, dW2, dWs; scratch dpre [N][H*W], dpooled [N][H*W][2], dgc, davg, dmx [N][C]. */
+int64_t vc_cbam_workspace_floats(int N, int H, int W, int C);
+int vc_cbam_fwd(int dtype, const void* x, const float* W1, const float* W2, const float* Ws, void* out, float* avg,
+                float* mx, int* argp, float* hid, float* gc, float* pooled, int* argc, float* gs, float* workspace,
+                int N, int H, int W, int C, int Ch, int k, vc_stream_t stream);
+int vc_cbam_bwd(int dtype, const void* x, const void* dout, const float* W1, const float* W2, const float* Ws,
+                const float* avg, const float* mx, const int* argp, const float* hid, const float* gc,
+                const float* pooled, const int* argc, const float* gs, void* dx, float* dW1, float* dW2, float* dWs,
+                float* dpre, float* dpooled, float* dgc, float* davg, float* dmx, int N, int H, int W, int C, int Ch,
+                int k, vc_stream_t stream);
+
 /* ---- Swin-T window attention / patch merging (timm swin_tiny_patch4_window7_224 behind
  * model_components.py:254, 412).  qkv [B*H*W][3C] in token order; window partition, cyclic shift, relative
  * position bias gather, shift mask, softmax and P.V are one kernel; head_dim is 32, window <= 7. */

@@ -609,7 +609,8 @@ class ChannelAttention(nn.Module):
                                 nn.Conv2d(channels // reduction, channels, 1, bias=False))
 
     def forward(self, x):  # [N, C, H, W] -> [N, C, 1, 1]
-        return torch.sigmoid(self.fc(x.mean((2, 3), keepdim=True)) + self.fc(x.amax((2, 3), keepdim=True)))
+        # (adaptive_max_pool2d / max(dim) send the gradient to the first maximal element, as the reference's modules do)
+        return torch.sigmoid(self.fc(x.mean((2, 3), keepdim=True)) + self.fc(F.adaptive_max_pool2d(x, 1)))
 
 
 class SpatialAttention(nn.Module):
@@ -620,7 +621,7 @@ class SpatialAttention(nn.Module):
         self.conv = nn.Conv2d(2, 1, kernel_size, padding=kernel_size // 2, bias=False)
 
     def forward(self, x):  # [N, C, H, W] -> [N, 1, H, W]
-        return torch.sigmoid(self.conv(torch.cat([x.mean(1, keepdim=True), x.amax(1, keepdim=True)], 1)))
+        return torch.sigmoid(self.conv(torch.cat([x.mean(1, keepdim=True), x.max(1, keepdim=True)[0]], 1)))
 
 
 class LocalFeatureExtraction(nn.Module):

@@ -76,7 +76,7 @@ def call(name, *args):
 def query(name, *args):
     """Call an entry point that returns a value (not a status code); ints are passed as C int."""
     fn = getattr(lib(), name)
-    if name in ("vc_lstm_persist_xchg_bytes", "vc_lstm_persist_bwd_xchg_bytes"):
+    if name in ("vc_lstm_persist_xchg_bytes", "vc_lstm_persist_bwd_xchg_bytes", "vc_cbam_workspace_floats"):
         fn.restype = ctypes.c_longlong
     return fn(*[ctypes.c_int(int(a)) if isinstance(a, (bool, int)) else a for a in args])
 
