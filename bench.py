@@ -293,6 +293,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
+    dump = os.environ.get("VC_BENCH_DUMP_LAUNCHES")
+    if dump and rank == 0:  # one line per contraction launch of the profiled steps, in launch order
+        with open(dump, "w") as fh:
+            for tag, flops, s, e, nbytes in prof:
+                fh.write(f"{tag} {flops / 1e9:.2f} GF {nbytes / 1e6:.1f} MB {s.elapsed_time(e) * 1e3:.1f} us\n")
     # per-kernel-family time from the HIP events recorded around each contraction launch
     fam = {}
     for tag, flops, s, e, nbytes in prof:
@@ -312,14 +317,16 @@ def main():
         # HBM bytes per launch of the same kernel family from the PMC passes (tools/pmc_bench.sh, separate runs of
         # this command with --no-graph; FETCH_SIZE doubled as gfx950 requires) -- None if they were never collected
         traffic, traffic_src, traffic_step = None, None, None
-        tfile = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        import glob
+        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_hbm_traffic.json")))  # newest round last
+        tfile = tfiles[-1] if tfiles else ""
         if args.model == "resnetcrnn" and args.arch == "resnet50" and B == 32 and os.path.exists(tfile):
             with open(tfile) as fh:
                 tj = json.load(fh)
             if "conv_fwd" in tj.get("families", {}):
                 traffic = tj["families"]["conv_fwd"]["traffic_bytes"]
                 traffic_step = tj["families"]["conv_fwd"].get("traffic_bytes_per_step")
-                traffic_src = "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+                traffic_src = f"profiles/{os.path.basename(tfile)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
         roof = {"bound": "mfma", "kernel": "igemm_nt_persist_kernel<0,*> (forward implicit-GEMM conv/linear)",
                 "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / MFMA_BF16_PEAK_TFLOPS, "frac_of_per_launch_roofline": floor_s / tm,

@@ -48,11 +48,15 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--only", default=None, help="run only the layer with this name (for counter collection)")
     ap.add_argument("--passes", default="fwd,dgrad,wgrad")
+    ap.add_argument("--flush", action="store_true",
+                    help="overwrite a 1 GiB buffer before every timed launch: operands come from HBM as inside a "
+                         "training step, not from the 256 MB infinity cache the previous repetition left warm")
     args = ap.parse_args()
     passes = args.passes.split(",")
     dev = torch.device("cuda:0")
     dt = torch.bfloat16
     tot = {"fwd": [0.0, 0.0], "dgrad": [0.0, 0.0], "wgrad": [0.0, 0.0]}
+    flush_buf = torch.zeros(256 << 20, device=dev) if args.flush else None
     print(f"{'layer':12s} {'N,H,W,Ci->Co k s':34s} {'cnt':>3s} {'GF':>8s} | {'fwd TF':>7s} {'ms':>6s} | {'dgrad TF':>8s} {'ms':>6s} |"
           f" {'wgrad TF':>8s} {'ms':>6s}")
     for name, N, H, W, Ci, Co, k, s, p, cnt in resnet50_shapes(args.frames):
@@ -75,6 +79,17 @@ def main():
         def run(fn):
             fn()
             torch.cuda.synchronize()
+            if args.flush:
+                total = 0.0
+                for _ in range(args.reps):
+                    flush_buf.add_(1.0)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    fn()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    total += e0.elapsed_time(e1)
+                return total / args.reps
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(args.reps):
