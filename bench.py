@@ -274,6 +274,7 @@ def main():
         loss = step()
     fence()
     elapsed = time.perf_counter() - t0
+    ops.check_lstm_error()  # a persistent LSTM kernel that timed out would have made the timed steps meaningless
     trace("timed region done")
     prof_steps = args.steps
     if mode == "eager":
