@@ -763,7 +763,9 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
   const int lchunk = pchunk ^ ((lrow >> 1) & 7);
   // k-tiles per tap; a single-tap layer (linear, 1x1 convolution) may have any channel count that is a
   // multiple of 8: the chunks of its last k-tile that lie beyond Ci read zeros
-  const int KS = g.ksplit;                       // > 1: single tap, Ci % (BK * KS) == 0, fp32 partial outputs
+  // > 1: single tap, Ci % (BK * KS) == 0, fp32 partial outputs (plain forward layers only: the epilogue variants are
+  // at their register limit and never run split)
+  const int KS = (EPI == EPI_NONE && MODE == 0 && !BL) ? g.ksplit : 1;
   const int ncb = (g.Ci + BK - 1) / BK / KS;     // k-tiles per tap (and slice)
   const int nk = g.kd * g.kh * g.kw * ncb;       // k-tiles per work unit (>= 1)
   const bool ktail = (g.Ci % BK) != 0;
