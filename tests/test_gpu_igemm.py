@@ -454,3 +454,45 @@ def test_forward_with_split_reduction(cuda, shape):
         torch.cuda.synchronize()
         assert not torch.isnan(ws).any()
         assert _rel(y1.float().cpu(), y0.float().cpu()) < (1e-5 if f32 else 8e-3)  # bf16: one ulp at the top
+
+
+@pytest.mark.parametrize("N,H,Ci,Co,k", [(512, 14, 256, 256, 3), (512, 14, 256, 1024, 1), (128, 56, 64, 64, 3),
+                                         (128, 56, 64, 256, 1), (128, 28, 512, 128, 1)],
+                         ids=["3x3_256", "1x1_256_1024", "3x3_64", "1x1_one_ktile", "1x1_512_128"])
+def test_persistent_kernel_repeats_bit_identically(cuda, N, H, Ci, Co, k):
+    """Forward and data gradient (bf16 outputs, no atomics anywhere) of whole-chip launches, twelve times each with a
+    256 MiB buffer rewritten in between: every repetition equals the first bit for bit, and the first equals the
+    naive kernel within accumulation order.  The persistent kernel's waits leave an output tile's stores in flight
+    while the next tile is staged; a wait that let a staged k-tile through early would show up here as a difference
+    that comes and goes."""
+    from video_classification_amd import _lib as L
+    g = torch.Generator().manual_seed(11)
+    p = k // 2
+    desc, (_, Ho, Wo) = _desc(N, 1, H, H, Ci, Co, (1, k, k), (1, 1, 1), (0, p, p))
+    d = L.int_array(desc)
+    taps = k * k
+    x = torch.randn(N, 1, H, H, Ci, generator=g).to(cuda, torch.bfloat16)
+    dy = torch.randn(N, 1, Ho, Wo, Co, generator=g).to(cuda, torch.bfloat16)
+    w = (torch.randn(Co, Ci, taps, generator=g) * 0.05).to(cuda)
+    b = torch.randn(Co, generator=g).to(cuda)
+    wf = torch.empty(Co, taps, Ci, device=cuda, dtype=torch.bfloat16)
+    wt = torch.empty(Ci, taps, Co, device=cuda, dtype=torch.bfloat16)
+    L.call("vc_pack_weight", 1, L.ptr(w), L.ptr(wf), L.ptr(wt), Co, Ci, taps, Ci, Co, L.stream())
+    flush = torch.empty(64 << 20, device=cuda)
+    first = None
+    for rep in range(12):
+        y = torch.empty(N, 1, Ho, Wo, Co, device=cuda, dtype=torch.bfloat16)
+        dx = torch.empty(N, 1, H, H, Ci, device=cuda, dtype=torch.bfloat16)
+        flush.fill_(float(rep))
+        L.call("vc_conv_fwd", d, 1, L.ptr(x), 0, L.ptr(wf), L.ptr(b), L.ptr(y), 0, 1, 0, 0, L.stream())
+        L.call("vc_conv_dgrad", d, 1, L.ptr(dy), 0, L.ptr(wt), L.ptr(dx), 0, 0, 0, L.stream())
+        torch.cuda.synchronize()
+        if first is None:
+            first = (y, dx)
+            yn = torch.empty(N, 1, Ho, Wo, Co, device=cuda, dtype=torch.float32)
+            L.call("vc_conv_fwd_naive_bf16", d, 0, L.ptr(x), L.ptr(wf), L.ptr(b), L.ptr(yn), 1, 1, L.stream())
+            torch.cuda.synchronize()
+            assert _rel(y.float(), yn) < 8e-3
+        else:
+            assert torch.equal(y, first[0]), f"forward differs in repetition {rep}"
+            assert torch.equal(dx, first[1]), f"data gradient differs in repetition {rep}"

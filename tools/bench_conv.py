@@ -46,7 +46,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=512)
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--only", default=None, help="run only the layer with this name (for counter collection)")
+    ap.add_argument("--only", default=None, help="run only the layers with these names, comma separated (for counter collection)")
     ap.add_argument("--passes", default="fwd,dgrad,wgrad")
     ap.add_argument("--flush", action="store_true",
                     help="overwrite a 1 GiB buffer before every timed launch: operands come from HBM as inside a "
@@ -60,7 +60,7 @@ def main():
     print(f"{'layer':12s} {'N,H,W,Ci->Co k s':34s} {'cnt':>3s} {'GF':>8s} | {'fwd TF':>7s} {'ms':>6s} | {'dgrad TF':>8s} {'ms':>6s} |"
           f" {'wgrad TF':>8s} {'ms':>6s}")
     for name, N, H, W, Ci, Co, k, s, p, cnt in resnet50_shapes(args.frames):
-        if args.only and name != args.only:
+        if args.only and name not in args.only.split(","):
             continue
         cip = (Ci + 7) // 8 * 8
         Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
