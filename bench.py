@@ -162,6 +162,8 @@ def main():
     ap.add_argument("--bucket-mb", type=int, default=32)
     ap.add_argument("--infer", action="store_true",
                     help="time the eval-mode forward (predict.py / save_predictions callers) instead of a training step")
+    ap.add_argument("--deterministic", action="store_true",
+                    help="trainer.set_deterministic(): ordered sums instead of fp32 atomics, steps repeat bit for bit")
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 8 if args.model in ("swinrnn", "clusterswin") else 32
@@ -189,8 +191,12 @@ def main():
     torch.cuda.set_device(dev)
 
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    if args.deterministic:
+        TR.set_deterministic(0)
     torch.manual_seed(0)
     model, shape, workload = build_workload(args, M, S)
+    if args.deterministic:
+        workload += ", deterministic mode"
     model = model.to(dev).set_compute_dtype(dt)
     opt = TR.get_optimizer(model, "adam", lr=1e-4, weight_decay=1e-4)
     trace("model and optimizer built")

@@ -39,6 +39,17 @@ typedef struct ihipStream_t* vc_stream_t; /* hipStream_t */
 /* ---- library ---- */
 int vc_version(void);
 const char* vc_last_error(void);
+/* Deterministic mode, the counterpart of torch.backends.cudnn.deterministic = True in set_deterministic
+ * (utils/common/training_utils.py:27-35).  on != 0: sums that blocks otherwise combine with fp32 atomics in whatever
+ * order they finish (weight / bias gradients, BatchNorm statistics and backward reductions, column sums, the mean
+ * loss) are added in a fixed order, so that a training step repeats bit for bit.  workspace: device memory of the
+ * CURRENT device (at least 2^20 floats; 2^26 cover the ResNet-50 CRNN step at 32 clips without cutting a weight
+ * gradient into fewer splits), owned by the caller, kept alive while the mode is on; call once per device, and issue
+ * the library's calls on one stream at a time per device.  on == 0 switches the mode off on every device.  Not
+ * covered: the LayerNorm gamma / beta gradients, the relative-position-bias gradient and the CBAM gradients of the
+ * Swin and fusion models. */
+int vc_set_deterministic(int on, float* workspace, size_t workspace_floats);
+int vc_get_deterministic(void);
 
 /* ---- dense contractions (MFMA implicit GEMM) ------------------------------------------------------
  * Replace nn.Conv2d (utils/common/model_components.py:91,96,101,106; torchvision ResNet convs behind

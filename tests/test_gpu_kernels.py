@@ -383,3 +383,30 @@ def test_persistent_lstm_matches_stepwise(cuda, T, B, In, H, layers, bidir):
     # same forward, backward recurrence per step vs persistent: only the summation order of dh differs
     for i in (1, 2, 3):
         assert (outs[1][i] - outs[2][i]).abs().max().item() < 2e-2 * outs[1][i].abs().max().item(), i
+
+
+@pytest.mark.parametrize("M,C", [(5000, 96), (3000, 768)])
+def test_layernorm_gradients_in_deterministic_mode(cuda, M, C):
+    """ops.set_deterministic: the LayerNorm parameter gradients (sums over M rows, blocks otherwise combined with
+    atomics) repeat bit for bit and agree with the default mode up to summation order."""
+    from video_classification_amd import ops
+    ln = nn.LayerNorm(C).to(cuda)
+    x = torch.randn(M, C, generator=torch.Generator().manual_seed(1)).to(cuda, torch.bfloat16)
+    dy = torch.randn(M, C, generator=torch.Generator().manual_seed(2)).to(cuda, torch.bfloat16)
+
+    def grads():
+        ln.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        ops.layer_norm(xi, ln).backward(dy)
+        torch.cuda.synchronize()
+        return ln.weight.grad.clone(), ln.bias.grad.clone(), xi.grad.clone()
+    base = grads()
+    ops.set_deterministic(True, workspace_mb=64)
+    try:
+        a, b = grads(), grads()
+    finally:
+        ops.set_deterministic(False)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    for u, v in zip(a, base):
+        assert G.max_rel(u.float().cpu(), v.float().cpu()) < 1e-4

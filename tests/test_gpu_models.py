@@ -601,3 +601,55 @@ def test_bottleneck_chain_reductions_in_dgrad_epilogue(cuda):
     G.report_against_noise_floor("dgrad-epilogue reductions vs separate pass", err, floor)
     assert max(err.values()) < 0.15, max(err, key=err.get)
     assert sorted(err.values())[len(err) // 2] < 0.05
+
+
+@pytest.mark.gpu
+def test_deterministic_mode_repeats_bit_for_bit(cuda):
+    """trainer.set_deterministic (reference: utils/common/training_utils.py:27): two training steps of the ResNet CRNN
+    from the same state give bit-identical losses, gradients and running statistics, and the same values as the default
+    mode up to summation order.  Without the mode the same two runs differ (fp32 atomics), which is what makes the
+    check meaningful."""
+    from video_classification_amd import modules as M, ops, trainer
+
+    import types
+    M.RESNET_LAYERS["tiny"] = (1, 1, 1, 1)
+    cfg = types.SimpleNamespace(CNN_fc_hidden1=64, CNN_fc_hidden2=48, CNN_embed_dim=32, dropout_p=0.0,
+                                use_pretrained=False, RNN_hidden_layers=2, RNN_hidden_nodes=32, RNN_FC_dim=16,
+                                num_classes=11, arch="tiny")
+
+    def run():
+        torch.manual_seed(3)
+        model = M.ResNetCRNNModel(cfg).to(cuda)
+        model.set_compute_dtype(torch.bfloat16)
+        model.train()
+        g = torch.Generator().manual_seed(4)
+        x = torch.randn(6, 4, 3, 96, 96, generator=g).to(cuda)
+        y = torch.randint(0, 11, (6,), generator=g).to(cuda)
+        loss = ops.cross_entropy(model(x), y)
+        loss.backward()
+        torch.cuda.synchronize()
+        res = {"loss": loss.detach().float().cpu().reshape(-1)}
+        for k, p in model.named_parameters():
+            res["grad." + k] = p.grad.detach().float().cpu()
+        for k, b in model.named_buffers():
+            if b.dtype.is_floating_point:
+                res["buf." + k] = b.detach().float().cpu()
+        return res
+
+    base1, base2 = run(), run()
+    differing = [k for k in base1 if not torch.equal(base1[k], base2[k])]
+    assert differing, "the default mode repeated exactly: this test no longer shows what the mode is for"
+    trainer.set_deterministic(5)
+    try:
+        assert ops.is_deterministic()
+        det1, det2 = run(), run()
+    finally:
+        ops.set_deterministic(False)
+    assert not ops.is_deterministic()
+    for k in det1:
+        assert torch.equal(det1[k], det2[k]), k
+    # same mathematics as the default mode: what differs is summation order (and what rounding makes of it)
+    import golden_util as GU
+    worst = max(GU.l2_rel(det1[k], base1[k]) for k in det1)
+    floor = max(GU.l2_rel(base2[k], base1[k]) for k in det1)
+    assert worst < 2 * floor + 5e-3, (worst, floor)

@@ -5,6 +5,56 @@
 
 namespace {
 thread_local char g_err[512] = "";
+
+constexpr int MAX_DEV = 64;
+int g_det = 0;
+float* g_det_ws[MAX_DEV] = {};
+size_t g_det_floats[MAX_DEV] = {};
+
+int current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  return dev;
+}
+
+// out[i] += ws[0][i] + ws[1][i] + ... + ws[slots - 1][i], added in that order
+__global__ void det_reduce_kernel(float* __restrict__ out, const float* __restrict__ ws, size_t n, int slots) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float a = 0.f;
+  for (int s = 0; s < slots; ++s) a += ws[(size_t)s * n + i];
+  out[i] += a;
+}
+}  // namespace
+
+bool vc_deterministic() { return g_det != 0; }
+
+size_t vc_det_capacity() {
+  const int dev = current_device();
+  return dev < 0 ? 0 : g_det_floats[dev];
+}
+
+float* vc_det_workspace(size_t floats, hipStream_t stream, const char* who) {
+  const int dev = current_device();
+  if (dev < 0 || !g_det_ws[dev] || g_det_floats[dev] < floats) {
+    vc_set_error("%s: deterministic mode needs a workspace of %zu floats on this device, vc_set_deterministic registered %zu",
+                 who, floats, dev < 0 ? (size_t)0 : g_det_floats[dev]);
+    return nullptr;
+  }
+  if (hipMemsetAsync(g_det_ws[dev], 0, floats * sizeof(float), stream) != hipSuccess) {
+    vc_set_error("%s: clearing the deterministic-mode workspace failed: %s", who, hipGetErrorString(hipGetLastError()));
+    return nullptr;
+  }
+  return g_det_ws[dev];
+}
+
+int vc_det_reduce(float* out, const float* ws, size_t n, int slots, hipStream_t stream) {
+  hipLaunchKernelGGL(det_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, out, ws, n, slots);
+  VC_LAUNCH_CHECK("vc_det_reduce");
+  return VC_OK;
 }
 
 void vc_set_error(const char* fmt, ...) {
@@ -31,5 +81,30 @@ extern "C" {
 int vc_version(void) { return 101; }
 
 const char* vc_last_error(void) { return g_err; }
+
+// on != 0: every sum that is otherwise combined with floating-point atomics (weight and bias gradients, BatchNorm
+// statistics and backward reductions, the loss) is added in a fixed order, so that a step repeats bit for bit.
+// `workspace` (device memory of the CURRENT device, `workspace_floats` floats, owned by the caller and kept alive while
+// the mode is on) holds the per-block partial sums; call once per device.  Calls that use it must be issued on one
+// stream at a time per device.  on == 0 switches the mode off for every device and forgets the workspaces.
+int vc_set_deterministic(int on, float* workspace, size_t workspace_floats) {
+  if (!on) {
+    g_det = 0;
+    for (int d = 0; d < MAX_DEV; ++d) {
+      g_det_ws[d] = nullptr;
+      g_det_floats[d] = 0;
+    }
+    return VC_OK;
+  }
+  const int dev = current_device();
+  VC_CHECK_ARG(dev >= 0, "vc_set_deterministic: no current device");
+  VC_CHECK_ARG(workspace && workspace_floats >= (1u << 20), "vc_set_deterministic: needs a workspace of at least 2^20 floats");
+  g_det_ws[dev] = workspace;
+  g_det_floats[dev] = workspace_floats;
+  g_det = 1;
+  return VC_OK;
+}
+
+int vc_get_deterministic(void) { return g_det; }
 
 }  // extern "C"

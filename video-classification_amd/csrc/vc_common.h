@@ -31,6 +31,15 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 void vc_set_error(const char* fmt, ...);
 int vc_device_cus();  // compute units of the current device (256 if no device answers)
+// Deterministic mode (vc_set_deterministic): sums that blocks otherwise combine with fp32 atomics, in whatever order
+// they finish, go through a workspace instead -- block (slot) s adds into ws[s * n + i], and vc_det_reduce then does
+// out[i] += ws[0 * n + i] + ws[1 * n + i] + ... in slot order.
+bool vc_deterministic();
+size_t vc_det_capacity();  // floats of the current device's workspace (0: none registered)
+// the current device's workspace with its first `floats` floats zeroed on `stream`; nullptr (and the error set) when
+// it is missing or too small
+float* vc_det_workspace(size_t floats, hipStream_t stream, const char* who);
+int vc_det_reduce(float* out, const float* ws, size_t n, int slots, hipStream_t stream);
 
 #define VC_CHECK_ARG(cond, ...)        \
   do {                                 \

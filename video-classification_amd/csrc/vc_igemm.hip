@@ -1079,7 +1079,7 @@ template <bool GLDS>
 __global__ __launch_bounds__(NTHR, 2) void igemm_tn_wgrad_bf16_kernel(ConvGeom g, const bf16* __restrict__ x,
                                                                       const bf16* __restrict__ dy, int ldy,
                                                                       float* __restrict__ dw, int m_per_split,
-                                                                      int ntiles, int tiles_col) {
+                                                                      int ntiles, int tiles_col, size_t split_stride) {
   __shared__ __attribute__((aligned(1024))) bf16 smem[2 * 2 * BK * 128];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1088,6 +1088,7 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_tn_wgrad_bf16_kernel(ConvGeom g
   int logical;
   xcd_remap(logical);
   const int split = logical / ntiles, tile = logical - split * ntiles;
+  dw += (size_t)split * split_stride;  // deterministic mode: a copy of the gradient per split, added in order afterwards
   const int tile_co = tile / tiles_col, tile_col = tile - tile_co * tiles_col;
   const int co0 = tile_co * 128, col0 = tile_col * 128;
   const int m_begin = split * m_per_split;
@@ -1243,7 +1244,7 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_tn_wgrad_fast_kernel(ConvGeom g
                                                                       const bf16* __restrict__ dy, int ldy,
                                                                       float* __restrict__ dw, int m_per_split,
                                                                       int ntiles, int tiles_col,
-                                                                      float* __restrict__ dbias) {
+                                                                      float* __restrict__ dbias, size_t split_stride) {
   constexpr int STAGE = BK * (TCO + TCOL);  // elements per pipeline stage: dY tile then X tile
   constexpr int LY = TCO / 8, RY = NTHR / LY, PY = BK / RY;     // dY: lanes per row, rows per pass, passes
   constexpr int LX = TCOL / 8, RX = NTHR / LX, PX = BK / RX;    // X likewise
@@ -1257,6 +1258,10 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_tn_wgrad_fast_kernel(ConvGeom g
   int logical;
   xcd_remap(logical);
   const int split = logical / ntiles, tile = logical - split * ntiles;
+  if (split_stride) {  // deterministic mode: a copy of both gradients per split, added in order afterwards
+    dw += (size_t)split * split_stride;
+    if (dbias) dbias += (size_t)split * g.Co;
+  }
   const int tile_co = tile / tiles_col, tile_col = tile - tile_co * tiles_col;
   const int co0 = tile_co * TCO, col0 = tile_col * TCOL;
   const int m_begin = split * m_per_split;
@@ -2192,27 +2197,53 @@ int vc_conv_wgrad(const int* desc, int dtype, const void* x, int ldx, const void
     const int split_cap = g.M / wgrad_min_rows_per_split() > 2 ? g.M / wgrad_min_rows_per_split() : 2;
     if (splits > split_cap) splits = split_cap;
     if (splits < 1) splits = 1;
+    // deterministic mode: every split adds into its own copy of dw (and dbias) in the workspace and the copies are
+    // added in split order afterwards; as many splits as the workspace holds copies (one split needs none)
+    const size_t nw = (size_t)g.Co * g.K, per_split = nw + (dbias_fused ? (size_t)g.Co : 0);
+    const bool det = vc_deterministic();
+    if (det && (size_t)splits * per_split > vc_det_capacity()) {
+      splits = (int)(vc_det_capacity() / per_split);
+      if (splits < 1) splits = 1;
+    }
     int mps = ceil_div(ceil_div(g.M, splits), BK) * BK;
     splits = ceil_div(g.M, mps);
     const dim3 grid(ntiles * splits);
+    const bool ordered = det && splits > 1;
+    float* const dw_user = dw_packed;
+    float* const db_user = dbias_fused;
+    size_t split_stride = 0;
+    if (ordered) {
+      float* ws = vc_det_workspace((size_t)splits * per_split, stream, "vc_conv_wgrad");
+      if (!ws) return VC_ERR_ARG;
+      dw_packed = ws;
+      if (dbias_fused) dbias_fused = ws + (size_t)splits * nw;
+      split_stride = nw;
+    }
     if (fast && tco == 64 && tcol == 64)
       hipLaunchKernelGGL((igemm_tn_wgrad_fast_kernel<64, 64>), grid, dim3(NTHR), 0, stream, g, (const bf16*)x,
-                         (const bf16*)dy, ldy_, dw_packed, mps, ntiles, tiles_col, dbias_fused);
+                         (const bf16*)dy, ldy_, dw_packed, mps, ntiles, tiles_col, dbias_fused, split_stride);
     else if (fast && tco == 64)
       hipLaunchKernelGGL((igemm_tn_wgrad_fast_kernel<64, 128>), grid, dim3(NTHR), 0, stream, g, (const bf16*)x,
-                         (const bf16*)dy, ldy_, dw_packed, mps, ntiles, tiles_col, dbias_fused);
+                         (const bf16*)dy, ldy_, dw_packed, mps, ntiles, tiles_col, dbias_fused, split_stride);
     else if (fast && tcol == 64)
       hipLaunchKernelGGL((igemm_tn_wgrad_fast_kernel<128, 64>), grid, dim3(NTHR), 0, stream, g, (const bf16*)x,
-                         (const bf16*)dy, ldy_, dw_packed, mps, ntiles, tiles_col, dbias_fused);
+                         (const bf16*)dy, ldy_, dw_packed, mps, ntiles, tiles_col, dbias_fused, split_stride);
     else if (fast)
       hipLaunchKernelGGL((igemm_tn_wgrad_fast_kernel<128, 128>), grid, dim3(NTHR), 0, stream, g, (const bf16*)x,
-                         (const bf16*)dy, ldy_, dw_packed, mps, ntiles, tiles_col, dbias_fused);
+                         (const bf16*)dy, ldy_, dw_packed, mps, ntiles, tiles_col, dbias_fused, split_stride);
     else if (use_glds())
       hipLaunchKernelGGL((igemm_tn_wgrad_bf16_kernel<true>), dim3(ntiles * splits), dim3(NTHR), 0, stream, g,
-                         (const bf16*)x, (const bf16*)dy, ldy_, dw_packed, mps, ntiles, tiles_col);
+                         (const bf16*)x, (const bf16*)dy, ldy_, dw_packed, mps, ntiles, tiles_col, split_stride);
     else
       hipLaunchKernelGGL((igemm_tn_wgrad_bf16_kernel<false>), dim3(ntiles * splits), dim3(NTHR), 0, stream, g,
-                         (const bf16*)x, (const bf16*)dy, ldy_, dw_packed, mps, ntiles, tiles_col);
+                         (const bf16*)x, (const bf16*)dy, ldy_, dw_packed, mps, ntiles, tiles_col, split_stride);
+    if (ordered) {
+      VC_LAUNCH_CHECK("vc_conv_wgrad");
+      if (int rc2 = vc_det_reduce(dw_user, dw_packed, nw, splits, stream)) return rc2;
+      if (db_user)
+        if (int rc2 = vc_det_reduce(db_user, dbias_fused, (size_t)g.Co, splits, stream)) return rc2;
+      dw_packed = dw_user;
+    }
   } else if (dtype == VC_BF16) {
     const int64_t total = (int64_t)g.Co * g.K;
     hipLaunchKernelGGL((wgrad_naive_kernel<bf16>), dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, stream, g,

@@ -298,20 +298,21 @@ __global__ void cast_kernel(const TI* __restrict__ a, TO* __restrict__ out, int6
 // column sums of [M][C] (bias gradients): out[c] += sum_m a[m][c]
 template <typename T>
 __global__ void colsum_kernel(const T* __restrict__ a, float* __restrict__ out, int M, int C, int lda,
-                              int rows_per_block) {
+                              int rows_per_block, size_t slot_stride) {
+  // slot_stride != 0 (deterministic mode): the block of row range y adds into its own copy y of out
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
   float acc = 0.f;
   for (int r = r0; r < r1; ++r) acc += to_f32(a[(size_t)r * lda + c]);
-  atomicAdd(out + c, acc);
+  atomicAdd(out + (size_t)blockIdx.y * slot_stride + c, acc);
 }
 
 // vectorised variant for dense rows with C % 8 == 0: 8 channels per lane, the block's row lanes are
 // reduced through LDS, one atomic per channel per block
 template <typename T>
 __global__ void colsum_vec_kernel(const T* __restrict__ a, float* __restrict__ out, int M, int C, int Cvalid,
-                                  int rows_per_block) {
+                                  int rows_per_block, size_t slot_stride) {
   __shared__ float red[NTHR][8];
   const int C8 = C >> 3;
   const int lanesC = C8 < NTHR ? C8 : NTHR;
@@ -343,7 +344,7 @@ __global__ void colsum_vec_kernel(const T* __restrict__ a, float* __restrict__ o
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i)
-        if (cc * 8 + i < Cvalid) atomicAdd(out + cc * 8 + i, acc[i]);
+        if (cc * 8 + i < Cvalid) atomicAdd(out + (size_t)blockIdx.x * slot_stride + cc * 8 + i, acc[i]);
     }
     __syncthreads();
   }
@@ -413,7 +414,9 @@ __global__ void lstm_cell_bwd_kernel(const T* __restrict__ dh_out, int ldo, cons
 template <typename TG>
 __global__ void ce_kernel(const float* __restrict__ logits, int ld, const int64_t* __restrict__ target,
                           float* __restrict__ loss, int64_t* __restrict__ pred, int* __restrict__ correct,
-                          TG* __restrict__ dlogits, int ldd, int B, int C, float loss_scale, float grad_scale) {
+                          TG* __restrict__ dlogits, int ldd, int B, int C, float loss_scale, float grad_scale,
+                          int loss_per_row) {
+  // loss_per_row (deterministic mode): loss[row] receives the row's term; the caller adds the rows in order
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= B) return;
@@ -443,7 +446,7 @@ __global__ void ce_kernel(const float* __restrict__ logits, int ld, const int64_
   const float lse = mx + logf(se);
   const int tgt = (int)target[row];
   if (lane == 0) {
-    atomicAdd(loss, (lse - lr[tgt]) * loss_scale);
+    atomicAdd(loss + (loss_per_row ? row : 0), (lse - lr[tgt]) * loss_scale);
     if (pred) pred[row] = mi;
     if (correct && mi == tgt) atomicAdd(correct, 1);
   }
@@ -624,22 +627,31 @@ int vc_cast(int src_dtype, int dst_dtype, const void* a, void* out, int64_t n, h
 // out[c] += sum over rows (caller zeroes or keeps a running gradient)
 int vc_colsum(int dtype, const void* a, float* out, int M, int C, int lda, hipStream_t stream) {
   VC_CHECK_ARG(a && out && M > 0 && C > 0 && lda >= C, "vc_colsum: bad argument");
-  if (lda % 8 == 0) {
+  const bool vec = lda % 8 == 0;
+  int rows_per_block = vec ? 256 : 64;
+  while (ceil_div(M, rows_per_block) > (vec ? 1024 : 512)) rows_per_block *= 2;
+  const int slots = ceil_div(M, rows_per_block);
+  // deterministic mode: a copy of out per block of rows, added in block order afterwards
+  const bool ordered = vc_deterministic() && slots > 1;
+  float* dst = out;
+  if (ordered) {
+    dst = vc_det_workspace((size_t)slots * C, stream, "vc_colsum");
+    if (!dst) return VC_ERR_ARG;
+  }
+  const size_t slot_stride = ordered ? (size_t)C : 0;
+  if (vec) {
     // rows are dense with `lda` (a multiple of 8) channels, of which the first C are summed
-    int rows_per_block = 256;
-    while (ceil_div(M, rows_per_block) > 1024) rows_per_block *= 2;
     DISPATCH_T(dtype, "vc_colsum",
-               hipLaunchKernelGGL((colsum_vec_kernel<T>), dim3(ceil_div(M, rows_per_block)), dim3(NTHR), 0, stream,
-                                  (const T*)a, out, M, lda, C, rows_per_block);)
+               hipLaunchKernelGGL((colsum_vec_kernel<T>), dim3(slots), dim3(NTHR), 0, stream, (const T*)a, dst, M, lda,
+                                  C, rows_per_block, slot_stride);)
   } else {
-    int rows_per_block = 64;
-    while (ceil_div(M, rows_per_block) > 512) rows_per_block *= 2;
-    dim3 grid(ceil_div(C, 64), ceil_div(M, rows_per_block));
+    dim3 grid(ceil_div(C, 64), slots);
     DISPATCH_T(dtype, "vc_colsum",
-               hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(64), 0, stream, (const T*)a, out, M, C, lda,
-                                  rows_per_block);)
+               hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(64), 0, stream, (const T*)a, dst, M, C, lda,
+                                  rows_per_block, slot_stride);)
   }
   VC_LAUNCH_CHECK("vc_colsum");
+  if (ordered) return vc_det_reduce(out, dst, (size_t)C, slots, stream);
   return VC_OK;
 }
 
@@ -672,14 +684,22 @@ int vc_ce_fwd_bwd(int grad_dtype, const float* logits, int ld, const int64_t* ta
   VC_CHECK_ARG(logits && target && loss, "vc_ce_fwd_bwd: null pointer");
   VC_CHECK_SHAPE(B > 0 && C > 0 && ld >= C && (!dlogits || ldd >= C), "vc_ce_fwd_bwd: bad shape");
   dim3 grid(ceil_div(B, 4)), blk(256);
+  // deterministic mode: the B terms of the mean are added in row order (the count of correct rows is an integer sum)
+  const bool ordered = vc_deterministic() && B > 1;
+  float* dst = loss;
+  if (ordered) {
+    dst = vc_det_workspace((size_t)B, stream, "vc_ce_fwd_bwd");
+    if (!dst) return VC_ERR_ARG;
+  }
   if (grad_dtype == VC_BF16)
-    hipLaunchKernelGGL((ce_kernel<bf16>), grid, blk, 0, stream, logits, ld, target, loss, pred, correct,
-                       (bf16*)dlogits, ldd, B, C, loss_scale, grad_scale);
+    hipLaunchKernelGGL((ce_kernel<bf16>), grid, blk, 0, stream, logits, ld, target, dst, pred, correct,
+                       (bf16*)dlogits, ldd, B, C, loss_scale, grad_scale, (int)ordered);
   else if (grad_dtype == VC_F32)
-    hipLaunchKernelGGL((ce_kernel<float>), grid, blk, 0, stream, logits, ld, target, loss, pred, correct,
-                       (float*)dlogits, ldd, B, C, loss_scale, grad_scale);
+    hipLaunchKernelGGL((ce_kernel<float>), grid, blk, 0, stream, logits, ld, target, dst, pred, correct,
+                       (float*)dlogits, ldd, B, C, loss_scale, grad_scale, (int)ordered);
   else { vc_set_error("vc_ce_fwd_bwd: unsupported dtype %d", grad_dtype); return VC_ERR_DTYPE; }
   VC_LAUNCH_CHECK("vc_ce_fwd_bwd");
+  if (ordered) return vc_det_reduce(loss, dst, 1, B, stream);  // one "table entry", B slots
   return VC_OK;
 }
 

@@ -26,7 +26,9 @@ __global__ void bn_reduce_kernel(const T* __restrict__ y, const T* dout, const T
                                  const float* __restrict__ mean, const float* __restrict__ invstd,
                                  const float* __restrict__ scale, const float* __restrict__ shift,
                                  float* __restrict__ s1, float* __restrict__ s2, int C, int rpg, int rows_per_block,
-                                 int relu, T* dz_out = nullptr, const uint8_t* __restrict__ bits = nullptr) {
+                                 int relu, T* dz_out = nullptr, const uint8_t* __restrict__ bits = nullptr,
+                                 size_t slot_stride = 0) {
+  // slot_stride != 0 (deterministic mode): block x of a group adds into its own copy x of the [G][C] tables
   __shared__ float red[2][NTHR][8];
   const int C8 = C >> 3;
   const int lanesC = C8 < NTHR ? C8 : NTHR;
@@ -161,8 +163,8 @@ __global__ void bn_reduce_kernel(const T* __restrict__ y, const T* dout, const T
           t1 += r1[k * CB + ch];
           t2 += r2[k * CB + ch];
         }
-        atomicAdd(s1 + g * C + cg, t1);
-        atomicAdd(s2 + g * C + cg, t2);
+        atomicAdd(s1 + (size_t)blockIdx.x * slot_stride + g * C + cg, t1);
+        atomicAdd(s2 + (size_t)blockIdx.x * slot_stride + g * C + cg, t2);
       }
     }
     __syncthreads();
@@ -177,7 +179,8 @@ __global__ void bn_reduce_kernel(const T* __restrict__ y, const T* dout, const T
 __global__ void bn_partial_reduce_kernel(const float* __restrict__ partial, float* __restrict__ sum,
                                          float* __restrict__ sumsq, int spg, int C, int chunk,
                                          const float* __restrict__ mean = nullptr,
-                                         const float* __restrict__ invstd = nullptr) {
+                                         const float* __restrict__ invstd = nullptr, size_t slot_stride = 0) {
+  // slot_stride != 0 (deterministic mode): the block of slab chunk y adds into its own copy y of the tables
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   const int g = blockIdx.z;
   if (c >= C) return;
@@ -189,8 +192,8 @@ __global__ void bn_partial_reduce_kernel(const float* __restrict__ partial, floa
     b += p[C + c];
   }
   if (mean) b = invstd[g * C + c] * (b - mean[g * C + c] * a);
-  atomicAdd(sum + g * C + c, a);
-  atomicAdd(sumsq + g * C + c, b);
+  atomicAdd(sum + (size_t)blockIdx.y * slot_stride + g * C + c, a);
+  atomicAdd(sumsq + (size_t)blockIdx.y * slot_stride + g * C + c, b);
 }
 
 __global__ void bn_finalize_kernel(float* __restrict__ sum, float* __restrict__ sumsq,
@@ -499,7 +502,7 @@ __global__ __launch_bounds__(NTHR) void bn_pool_bwd_kernel(
     const T* __restrict__ y, const T* __restrict__ dyp, const uint8_t* __restrict__ idx,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ scale,
     const float* __restrict__ shift, float* __restrict__ s1, float* __restrict__ s2, T* __restrict__ dy, int C, int H,
-    int W, int Ho, int Wo, int k, int s, int p, int rpg, int rows_per_block, float inv_cnt) {
+    int W, int Ho, int Wo, int k, int s, int p, int rpg, int rows_per_block, float inv_cnt, size_t slot_stride) {
   __shared__ float red[2][NTHR][8];
   const int C8 = C >> 3, g = blockIdx.y;
   const RowWalk w = row_walk(C8, rpg, rows_per_block);
@@ -566,8 +569,8 @@ __global__ __launch_bounds__(NTHR) void bn_pool_bwd_kernel(
             t1 += r1[q * CB + ch];
             t2 += r2[q * CB + ch];
           }
-          atomicAdd(s1 + g * C + cg, t1);
-          atomicAdd(s2 + g * C + cg, t2);
+          atomicAdd(s1 + (size_t)blockIdx.x * slot_stride + g * C + cg, t1);
+          atomicAdd(s2 + (size_t)blockIdx.x * slot_stride + g * C + cg, t2);
         }
       }
       __syncthreads();
@@ -656,7 +659,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
                                                       const float* __restrict__ gamma, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, T* __restrict__ dx,
                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int M,
-                                                      int C, int rows_per_block, const T* __restrict__ add) {
+                                                      int C, int rows_per_block, const T* __restrict__ add,
+                                                      size_t slot_stride) {
+  // slot_stride != 0 (deterministic mode): the row groups of a block fold their sums one after the other instead of
+  // with LDS atomics, and the block adds into its own copy of dgamma / dbeta (copy blockIdx.x)
   extern __shared__ float lds[];  // [2][C]
   constexpr int RPB = 256 / LPR;
   const int C8 = C >> 3;
@@ -720,18 +726,39 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
       }
     }
   }
+  if (slot_stride) {
+    for (int turn = 0; turn < RPB; ++turn) {  // row group `turn` adds, the others wait: a fixed order
+      if (rsl == turn) {
 #pragma unroll
-  for (int k = 0; k < NCH; ++k) {
-    const int cc = sub + LPR * k;
-    if (cc < C8) {
+        for (int k = 0; k < NCH; ++k) {
+          const int cc = sub + LPR * k;
+          if (cc < C8) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        atomicAdd(&lds[cc * 8 + i], pg[k][i]);
-        atomicAdd(&lds[C + cc * 8 + i], pb[k][i]);
+            for (int i = 0; i < 8; ++i) {
+              lds[cc * 8 + i] += pg[k][i];
+              lds[C + cc * 8 + i] += pb[k][i];
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int cc = sub + LPR * k;
+      if (cc < C8) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          atomicAdd(&lds[cc * 8 + i], pg[k][i]);
+          atomicAdd(&lds[C + cc * 8 + i], pb[k][i]);
+        }
       }
     }
+    __syncthreads();
   }
-  __syncthreads();
+  dgamma += (size_t)blockIdx.x * slot_stride;
+  dbeta += (size_t)blockIdx.x * slot_stride;
   for (int i = threadIdx.x; i < C; i += blockDim.x) {
     atomicAdd(dgamma + i, lds[i]);
     atomicAdd(dbeta + i, lds[C + i]);
@@ -757,9 +784,20 @@ int launch_reduce(const void* y, const void* dout, const void* act, const float*
   int rows_per_block = 16 * RL;
   while (rows_per_block < rpg && (int64_t)ceil_div(rpg, rows_per_block) * G > bn_reduce_blocks()) rows_per_block *= 2;
   dim3 grid(ceil_div(rpg, rows_per_block), G);
+  if (vc_deterministic() && grid.x > 1) {
+    // every block adds into its own copy of the two tables; the copies are then added in block order
+    const size_t n = (size_t)G * C;
+    float* ws = vc_det_workspace(2 * n * grid.x, stream, "BatchNorm reduction");
+    if (!ws) return VC_ERR_ARG;
+    hipLaunchKernelGGL((bn_reduce_kernel<T, MODE, WRITE_DZ>), grid, dim3(NTHR), 0, stream, (const T*)y, (const T*)dout,
+                       (const T*)act, mean, invstd, scale, shift, ws, ws + n * grid.x, C, rpg, rows_per_block, relu,
+                       (T*)dz_out, bits, n);
+    vc_det_reduce(s1, ws, n, (int)grid.x, stream);
+    return vc_det_reduce(s2, ws + n * grid.x, n, (int)grid.x, stream);
+  }
   hipLaunchKernelGGL((bn_reduce_kernel<T, MODE, WRITE_DZ>), grid, dim3(NTHR), 0, stream, (const T*)y, (const T*)dout,
                      (const T*)act, mean, invstd, scale, shift, s1, s2, C, rpg, rows_per_block, relu, (T*)dz_out,
-                     bits);
+                     bits, (size_t)0);
   return VC_OK;
 }
 
@@ -772,6 +810,27 @@ inline int apply_rows_per_block(int G, int rpg, int C) {
   return rows;
 }
 
+// sum / sumsq [G][C] += the slab sums of `partial`, a block per (256 channels, chunk of slabs, group); deterministic
+// mode: every chunk adds into its own copy of the tables, the copies are added in chunk order afterwards
+int launch_partial_reduce(const float* partial, float* sum, float* sumsq, int G, int spg, int C, const float* mean,
+                          const float* invstd, hipStream_t stream) {
+  int chunk = 16;
+  while (ceil_div(spg, chunk) * G * ceil_div(C, 256) > 2048) chunk *= 2;
+  const dim3 grid(ceil_div(C, 256), ceil_div(spg, chunk), G);
+  if (vc_deterministic() && grid.y > 1) {
+    const size_t n = (size_t)G * C;
+    float* ws = vc_det_workspace(2 * n * grid.y, stream, "BatchNorm slab sums");
+    if (!ws) return VC_ERR_ARG;
+    hipLaunchKernelGGL(bn_partial_reduce_kernel, grid, dim3(256), 0, stream, partial, ws, ws + n * grid.y, spg, C, chunk,
+                       mean, invstd, n);
+    vc_det_reduce(sum, ws, n, (int)grid.y, stream);
+    return vc_det_reduce(sumsq, ws + n * grid.y, n, (int)grid.y, stream);
+  }
+  hipLaunchKernelGGL(bn_partial_reduce_kernel, grid, dim3(256), 0, stream, partial, sum, sumsq, spg, C, chunk, mean,
+                     invstd, (size_t)0);
+  return VC_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -780,11 +839,13 @@ extern "C" {
 int vc_bn_stats(int dtype, const void* y, float* sum, float* sumsq, int G, int rpg, int C, hipStream_t stream) {
   VC_CHECK_ARG(y && sum && sumsq, "vc_bn_stats: null pointer");
   VC_CHECK_SHAPE(C % 8 == 0 && G > 0 && rpg > 0, "vc_bn_stats: need C %% 8 == 0 (C=%d)", C);
+  int rc = VC_OK;
   if (dtype == VC_BF16)
-    launch_reduce<bf16, 0>(y, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, sum, sumsq, G, rpg, C, 0, stream);
+    rc = launch_reduce<bf16, 0>(y, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, sum, sumsq, G, rpg, C, 0, stream);
   else if (dtype == VC_F32)
-    launch_reduce<float, 0>(y, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, sum, sumsq, G, rpg, C, 0, stream);
+    rc = launch_reduce<float, 0>(y, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, sum, sumsq, G, rpg, C, 0, stream);
   else { vc_set_error("vc_bn_stats: unsupported dtype %d", dtype); return VC_ERR_DTYPE; }
+  if (rc) return rc;
   VC_LAUNCH_CHECK("vc_bn_stats");
   return VC_OK;
 }
@@ -795,11 +856,7 @@ int vc_bn_stats_from_partial(const float* partial, float* sum, float* sumsq, int
                              hipStream_t stream) {
   VC_CHECK_ARG(partial && sum && sumsq, "vc_bn_stats_from_partial: null pointer");
   VC_CHECK_SHAPE(G > 0 && G < 65536 && spg > 0 && C > 0, "vc_bn_stats_from_partial: bad shape");
-  int chunk = 16;
-  while (ceil_div(spg, chunk) * G * ceil_div(C, 256) > 2048) chunk *= 2;
-  const dim3 grid(ceil_div(C, 256), ceil_div(spg, chunk), G);
-  hipLaunchKernelGGL(bn_partial_reduce_kernel, grid, dim3(256), 0, stream, partial, sum, sumsq, spg, C, chunk,
-                     (const float*)nullptr, (const float*)nullptr);
+  if (int rc = launch_partial_reduce(partial, sum, sumsq, G, spg, C, nullptr, nullptr, stream)) return rc;
   VC_LAUNCH_CHECK("vc_bn_stats_from_partial");
   return VC_OK;
 }
@@ -810,11 +867,7 @@ int vc_bn_bwd_sums_from_partial(const float* partial, const float* mean, const f
                                 int G, int spg, int C, hipStream_t stream) {
   VC_CHECK_ARG(partial && mean && invstd && s1 && s2, "vc_bn_bwd_sums_from_partial: null pointer");
   VC_CHECK_SHAPE(G > 0 && G < 65536 && spg > 0 && C > 0, "vc_bn_bwd_sums_from_partial: bad shape");
-  int chunk = 16;
-  while (ceil_div(spg, chunk) * G * ceil_div(C, 256) > 2048) chunk *= 2;
-  const dim3 grid(ceil_div(C, 256), ceil_div(spg, chunk), G);
-  hipLaunchKernelGGL(bn_partial_reduce_kernel, grid, dim3(256), 0, stream, partial, s1, s2, spg, C, chunk, mean,
-                     invstd);
+  if (int rc = launch_partial_reduce(partial, s1, s2, G, spg, C, mean, invstd, stream)) return rc;
   VC_LAUNCH_CHECK("vc_bn_bwd_sums_from_partial");
   return VC_OK;
 }
@@ -889,9 +942,13 @@ int vc_bn_bwd_reduce(int dtype, const void* y, const void* dout, const void* act
   VC_CHECK_ARG(y && dout && mean && invstd && s1 && s2 && (!relu || act || (scale && shift)),
                "vc_bn_bwd_reduce: null pointer");
   VC_CHECK_SHAPE(C % 8 == 0, "vc_bn_bwd_reduce: need C %% 8 == 0 (C=%d)", C);
-  if (dtype == VC_BF16) launch_reduce<bf16, 1>(y, dout, act, mean, invstd, scale, shift, s1, s2, G, rpg, C, relu, stream);
-  else if (dtype == VC_F32) launch_reduce<float, 1>(y, dout, act, mean, invstd, scale, shift, s1, s2, G, rpg, C, relu, stream);
+  int rc = VC_OK;
+  if (dtype == VC_BF16)
+    rc = launch_reduce<bf16, 1>(y, dout, act, mean, invstd, scale, shift, s1, s2, G, rpg, C, relu, stream);
+  else if (dtype == VC_F32)
+    rc = launch_reduce<float, 1>(y, dout, act, mean, invstd, scale, shift, s1, s2, G, rpg, C, relu, stream);
   else { vc_set_error("vc_bn_bwd_reduce: unsupported dtype %d", dtype); return VC_ERR_DTYPE; }
+  if (rc) return rc;
   VC_LAUNCH_CHECK("vc_bn_bwd_reduce");
   return VC_OK;
 }
@@ -904,13 +961,15 @@ int vc_bn_bwd_reduce_mask(int dtype, const void* y, void* dout, const uint8_t* b
                           const float* invstd, float* s1, float* s2, int G, int rpg, int C, hipStream_t stream) {
   VC_CHECK_ARG(y && dout && bits && mean && invstd && s1 && s2, "vc_bn_bwd_reduce_mask: null pointer");
   VC_CHECK_SHAPE(C % 8 == 0, "vc_bn_bwd_reduce_mask: need C %% 8 == 0 (C=%d)", C);
+  int rc = VC_OK;
   if (dtype == VC_BF16)
-    launch_reduce<bf16, 1, true>(y, dout, nullptr, mean, invstd, nullptr, nullptr, s1, s2, G, rpg, C, 1, stream, dout,
-                                 bits);
+    rc = launch_reduce<bf16, 1, true>(y, dout, nullptr, mean, invstd, nullptr, nullptr, s1, s2, G, rpg, C, 1, stream, dout,
+                                      bits);
   else if (dtype == VC_F32)
-    launch_reduce<float, 1, true>(y, dout, nullptr, mean, invstd, nullptr, nullptr, s1, s2, G, rpg, C, 1, stream, dout,
-                                  bits);
+    rc = launch_reduce<float, 1, true>(y, dout, nullptr, mean, invstd, nullptr, nullptr, s1, s2, G, rpg, C, 1, stream,
+                                       dout, bits);
   else { vc_set_error("vc_bn_bwd_reduce_mask: unsupported dtype %d", dtype); return VC_ERR_DTYPE; }
+  if (rc) return rc;
   VC_LAUNCH_CHECK("vc_bn_bwd_reduce_mask");
   return VC_OK;
 }
@@ -981,9 +1040,22 @@ int vc_bn_pool_bwd(int dtype, int phase, const void* y, const void* dyp, const u
     while (rows < 32 * RL && (int64_t)ceil_div(rpg, rows * 2) * G >= 4096) rows *= 2;
   }
   const dim3 grid(ceil_div(rpg, rows), G);
+  // deterministic mode, phase 0: a copy of the two tables per block, added in block order afterwards
+  const bool ordered = phase == 0 && vc_deterministic() && grid.x > 1;
+  const size_t n = (size_t)G * C;
+  float* const s1_user = s1;
+  float* const s2_user = s2;
+  size_t slot_stride = 0;
+  if (ordered) {
+    float* ws = vc_det_workspace(2 * n * grid.x, stream, "vc_bn_pool_bwd");
+    if (!ws) return VC_ERR_ARG;
+    s1 = ws;
+    s2 = ws + n * grid.x;
+    slot_stride = n;
+  }
 #define VC_BN_POOL_BWD(T, MODE)                                                                                        \
   hipLaunchKernelGGL((bn_pool_bwd_kernel<T, MODE>), grid, dim3(NTHR), 0, stream, (const T*)y, (const T*)dyp, idx, mean, \
-                     invstd, scale, shift, s1, s2, (T*)dy, C, H, W, Ho, Wo, k, s, p, rpg, rows, inv_cnt)
+                     invstd, scale, shift, s1, s2, (T*)dy, C, H, W, Ho, Wo, k, s, p, rpg, rows, inv_cnt, slot_stride)
   if (dtype == VC_BF16) {
     if (phase == 0) VC_BN_POOL_BWD(bf16, 0); else VC_BN_POOL_BWD(bf16, 1);
   } else if (dtype == VC_F32) {
@@ -991,6 +1063,10 @@ int vc_bn_pool_bwd(int dtype, int phase, const void* y, const void* dyp, const u
   } else { vc_set_error("vc_bn_pool_bwd: unsupported dtype %d", dtype); return VC_ERR_DTYPE; }
 #undef VC_BN_POOL_BWD
   VC_LAUNCH_CHECK("vc_bn_pool_bwd");
+  if (ordered) {
+    vc_det_reduce(s1_user, s1, n, (int)grid.x, stream);
+    return vc_det_reduce(s2_user, s2, n, (int)grid.x, stream);
+  }
   return VC_OK;
 }
 
@@ -1045,9 +1121,21 @@ int vc_layernorm_bwd_add(int dtype, const void* x, const void* dout, const float
   while (ceil_div(M, rows_per_block) > 1024) rows_per_block *= 2;
   dim3 grid(ceil_div(M, rows_per_block));
   const size_t lds = 2 * (size_t)C * sizeof(float);
+  // deterministic mode: a copy of dgamma / dbeta per block, added in block order afterwards
+  const bool ordered = vc_deterministic();
+  float* const dg_user = dgamma;
+  float* const db_user = dbeta;
+  size_t slot_stride = 0;
+  if (ordered) {
+    float* ws = vc_det_workspace(2 * (size_t)C * grid.x, stream, "vc_layernorm_bwd");
+    if (!ws) return VC_ERR_ARG;
+    dgamma = ws;
+    dbeta = ws + (size_t)C * grid.x;
+    slot_stride = (size_t)C;
+  }
 #define VC_LN_BWD(T, LPR, NCH)                                                                                  \
   hipLaunchKernelGGL((ln_bwd_kernel<T, LPR, NCH>), grid, dim3(256), lds, stream, (const T*)x, (const T*)dout,   \
-                     gamma, mean, rstd, (T*)dx, dgamma, dbeta, M, C, rows_per_block, (const T*)add)
+                     gamma, mean, rstd, (T*)dx, dgamma, dbeta, M, C, rows_per_block, (const T*)add, slot_stride)
 #define VC_LN_BWD_ALL(T)                                       \
   if (lpr == 16) VC_LN_BWD(T, 16, 1);                          \
   else if (lpr == 32) VC_LN_BWD(T, 32, 1);                     \
@@ -1060,6 +1148,10 @@ int vc_layernorm_bwd_add(int dtype, const void* x, const void* dout, const float
 #undef VC_LN_BWD_ALL
 #undef VC_LN_BWD
   VC_LAUNCH_CHECK("vc_layernorm_bwd");
+  if (ordered) {
+    vc_det_reduce(dg_user, dgamma, (size_t)C, (int)grid.x, stream);
+    return vc_det_reduce(db_user, dbeta, (size_t)C, (int)grid.x, stream);
+  }
   return VC_OK;
 }
 

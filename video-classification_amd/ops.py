@@ -55,6 +55,30 @@ def _grad_buf(p):
     return p.grad
 
 
+_det_workspaces = {}
+
+
+def set_deterministic(on=True, workspace_mb=256):
+    """Bit-for-bit repeatable steps (the counterpart of torch.backends.cudnn.deterministic = True): sums that the kernels
+    otherwise combine with fp32 atomics are added in a fixed order, through a workspace of `workspace_mb` MiB that is
+    registered with the library for the current device.  Call once per device a model runs on.  About 10 % slower."""
+    global WGRAD_STREAM
+    if not on:
+        L.call("vc_set_deterministic", 0, L.ptr(None), L.i64(0))
+        _det_workspaces.clear()
+        return
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ws = _det_workspaces.get(dev)
+    if ws is None or ws.numel() != workspace_mb << 18:
+        ws = _det_workspaces[dev] = torch.empty(workspace_mb << 18, device=dev, dtype=torch.float32)
+    WGRAD_STREAM = False  # the workspace is shared by every call: one stream at a time
+    L.call("vc_set_deterministic", 1, L.ptr(ws), L.i64(ws.numel()))
+
+
+def is_deterministic():
+    return bool(L.query("vc_get_deterministic"))
+
+
 _grad_ready_hook = None
 
 

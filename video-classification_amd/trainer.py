@@ -186,6 +186,20 @@ class FusedOptimizer(torch.optim.Optimizer):
         self.sync_lr()
 
 
+def set_deterministic(seed=42):
+    """Seeds Python, numpy and torch and makes every step repeat bit for bit on the device (reference:
+    utils/common/training_utils.py:27-35, whose cudnn.deterministic = True is ops.set_deterministic here)."""
+    import random
+
+    import numpy as np
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+        ops.set_deterministic(True)
+
+
 def get_optimizer(model, optimizer_name="adam", lr=0.001, weight_decay=1e-4):
     """Same factory signature as the reference (training_utils.py:311-331)."""
     return FusedOptimizer(model, optimizer_name, lr=lr, weight_decay=weight_decay)
