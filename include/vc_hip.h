@@ -108,6 +108,11 @@ int vc_conv_epilogue_side_supported(const int* desc, int dtype, int mode);
 int vc_conv_fwd_residual(const int* desc, int dtype, const void* x, const void* w_packed, const float* bias,
                          const void* residual, const float* row_scale, int rows_per_sample, void* y,
                          vc_stream_t stream);
+/* y = relu(conv(x) + bias + residual): torchvision Bottleneck's out = relu(bn3(conv3(.)) + identity) in EVAL mode, the
+ * BatchNorm folded into the convolution's weights and bias (predict.py / validate_epoch callers behind
+ * model_components.py:164-191).  Geometries as vc_conv_fwd_residual. */
+int vc_conv_fwd_residual_relu(const int* desc, int dtype, const void* x, const void* w_packed, const float* bias,
+                              const void* residual, void* y, vc_stream_t stream);
 int vc_conv_dgrad_gelu(const int* desc, int dtype, const void* dy, const void* w_packed_t, const void* pre, void* dx,
                        vc_stream_t stream);
 /* dw_packed (fp32 [co][taps][ci]) is accumulated into with atomics: the caller zeroes it.  dbias (nullable, fp32

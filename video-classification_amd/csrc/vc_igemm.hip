@@ -653,15 +653,21 @@ __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[
       }
     } else if (EPI == EPI_RESIDUAL || EPI == EPI_GELU_BWD) {  // host guarantees vec
       if (op) {
-        // EPI_RESIDUAL with a row scale (stochastic depth): tail_bits carries fp32 scales, one per `relu` rows
+        // EPI_RESIDUAL with a row scale (stochastic depth): tail_bits carries fp32 scales, one per `relu` rows;
+        // without one, relu < 0 asks for a ReLU AFTER the residual has been added
         float rs = 1.f;
         if (EPI == EPI_RESIDUAL && tail_bits) rs = reinterpret_cast<const float*>(tail_bits)[m / relu];
+        const bool relu_sum = EPI == EPI_RESIDUAL && relu < 0;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float t = (float)v[e];
           if (beta) t += (float)oldv[it][e];
-          if (EPI == EPI_RESIDUAL) t = fmaf(t, rs, (float)tyv[it][e]);
-          else t *= gelu_grad_dev((float)tyv[it][e]);
+          if (EPI == EPI_RESIDUAL) {
+            t = fmaf(t, rs, (float)tyv[it][e]);
+            if (relu_sum) t = fmaxf(t, 0.f);
+          } else {
+            t *= gelu_grad_dev((float)tyv[it][e]);
+          }
           v[e] = (bf16)t;
         }
         *reinterpret_cast<bf16x8*>(op) = v;
@@ -2123,6 +2129,23 @@ int vc_conv_fwd_residual(const int* desc, int dtype, const void* x, const void* 
   launch_persist<0, 128, EPI_RESIDUAL>(g, grid, stream, x, w_packed, bias, y, row_scale ? rows_per_sample : 0, 0, 0,
                                        tiles, nullptr, residual, reinterpret_cast<const uint8_t*>(row_scale));
   VC_LAUNCH_CHECK("vc_conv_fwd_residual");
+  return VC_OK;
+}
+
+// y = relu(conv(x) + bias + residual): the tail of a residual block whose BatchNorm has been folded into the
+// convolution (eval mode).  Same geometries as vc_conv_fwd_residual.
+int vc_conv_fwd_residual_relu(const int* desc, int dtype, const void* x, const void* w_packed, const float* bias,
+                              const void* residual, void* y, hipStream_t stream) {
+  ConvGeom g;
+  int rc = fill_geom(g, desc, 0, "vc_conv_fwd_residual_relu");
+  if (rc) return rc;
+  VC_CHECK_ARG(x && w_packed && residual && y, "vc_conv_fwd_residual_relu: null pointer");
+  VC_CHECK_SHAPE(dgrad_tail_eligible(g, dtype),
+                 "vc_conv_fwd_residual_relu: unsupported geometry (ask vc_conv_epilogue_side_supported)");
+  const int tiles = ceil_div(g.M, BM) * ceil_div(g.Co, BN);
+  const int grid = tiles < nt_persist_blocks() ? tiles : nt_persist_blocks();
+  launch_persist<0, 128, EPI_RESIDUAL>(g, grid, stream, x, w_packed, bias, y, -1, 0, 0, tiles, nullptr, residual, nullptr);
+  VC_LAUNCH_CHECK("vc_conv_fwd_residual_relu");
   return VC_OK;
 }
 

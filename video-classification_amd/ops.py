@@ -638,11 +638,69 @@ def conv(x, weight, bias=None, kernel=1, stride=1, padding=0, relu=False, out_f3
     return _Conv.apply(x, weight, bias, kernel, stride, padding, relu, out_f32, ci, join, 0)[0]
 
 
+# VC_FOLD_EVAL_BN=0 keeps eval-mode BatchNorm as a pass of its own behind the convolution (A/B measurements)
+FOLD_EVAL_BN = os.environ.get("VC_FOLD_EVAL_BN", "1") != "0"
+_bn_stats_epoch = 0  # moves whenever a training-mode BatchNorm has rewritten running statistics through raw pointers
+
+
+def _folded_bn_weights(weight, bias, bn):
+    """(weight * s, beta + (bias - running_mean) * s) with s = gamma / sqrt(running_var + eps) per output channel: the
+    convolution that equals BatchNorm(conv(x)) in eval mode.  fp32, cached on the BatchNorm module while neither the
+    parameters nor the running statistics have moved."""
+    key = (weight.data_ptr(), weight._version, _weights_epoch, _bn_stats_epoch, bn.running_mean._version,
+           bn.running_var._version, None if bn.weight is None else bn.weight._version,
+           None if bn.bias is None else bn.bias._version, None if bias is None else bias._version)
+    cache = getattr(bn, "_vc_fold", None)
+    if cache is not None and cache[0] == key:
+        return cache[1], cache[2]
+    with torch.no_grad():
+        s = torch.rsqrt(bn.running_var.float() + bn.eps)
+        if bn.weight is not None:
+            s = s * bn.weight.float()
+        wf = (weight.detach().float() * s.view(-1, *([1] * (weight.dim() - 1)))).contiguous()
+        b0 = -bn.running_mean.float() if bias is None else bias.detach().float() - bn.running_mean.float()
+        bf = b0 * s
+        if bn.bias is not None:
+            bf = bf + bn.bias.float()
+    object.__setattr__(bn, "_vc_fold", (key, wf, bf.contiguous()))
+    return wf, bf
+
+
+def _conv_folded_bn(x, weight, bias, bn, kernel, stride, padding, relu, residual):
+    """Eval-mode conv -> BatchNorm (-> + residual) (-> ReLU) as ONE convolution with folded weights: the activation is
+    written once, by the GEMM's epilogue (inference only: no autograd graph is recorded)."""
+    wf, bf = _folded_bn_weights(weight, bias, bn)
+    if residual is None:
+        return _Conv.apply(x, wf, bf, kernel, stride, padding, bool(relu), False, None, None, 0)[0]
+    x = x.contiguous()
+    N, D, H, W, cip = x.shape
+    co, ci = wf.shape[0], wf.shape[1]
+    k, st, p = _triple(kernel), _triple(stride), _triple(padding)
+    taps = k[0] * k[1] * k[2]
+    cop = pad8(co)
+    Do, Ho, Wo = [(i + 2 * pp - kk) // ss + 1 for i, kk, ss, pp in zip((D, H, W), k, st, p)]
+    desc = L.int_array([N, D, H, W, cip, Do, Ho, Wo, cop, *k, *st, *p])
+    code = L.dtype_code(x.dtype)
+    res = residual.contiguous()
+    if (relu and cop == co and tuple(res.shape) == (N, Do, Ho, Wo, cop) and res.dtype == x.dtype and
+            L.query("vc_conv_epilogue_side_supported", desc, code, 0) == 1):
+        wp, _ = _packed_weights(wf, ci, taps, cip, cop, x.dtype, want_t=False)
+        y = torch.empty(N, Do, Ho, Wo, cop, device=x.device, dtype=x.dtype)
+        L.call("vc_conv_fwd_residual_relu", desc, code, L.ptr(x), L.ptr(wp), L.ptr(bf), L.ptr(res), L.ptr(y), L.stream())
+        return y
+    y = _Conv.apply(x, wf, bf, kernel, stride, padding, False, False, None, None, 0)[0]
+    y = elementwise(0, y, cast(res.view(y.shape), y.dtype))
+    return elementwise(2, y) if relu else y
+
+
 def conv_bn(x, weight, bn, groups, bias=None, kernel=1, stride=1, padding=0, relu=False, residual=None, join=None,
             res_join=None, grad_inplace=False, pool=None, single_use=False):
     """BatchNorm(conv(x)) (+ residual, ReLU).  In training the convolution's epilogue also writes the slab sums
     the BatchNorm statistics are taken from, where the geometry allows it (otherwise a separate pass reads y)."""
     training = bn.training or bn.running_mean is None
+    if (not training and FOLD_EVAL_BN and pool is None and join is None and not torch.is_grad_enabled() and
+            x.dtype == torch.bfloat16):
+        return _conv_folded_bn(x, weight, bias, bn, kernel, stride, padding, relu, residual)
     y, partial, _ = _Conv.apply(x, weight, bias, kernel, stride, padding, False, False, None, join,
                                 groups if training else 0)
     if pool is not None:  # (k, s, p) of the max-pool that follows BatchNorm + ReLU
@@ -705,6 +763,8 @@ class _BatchNorm(torch.autograd.Function):
             if M % G:
                 raise RuntimeError(f"batch_norm: {M} rows do not split into {G} groups")
             rpg = M // G
+            global _bn_stats_epoch
+            _bn_stats_epoch += 1  # running statistics are rewritten through raw pointers: folded weights go stale
             sums = _zero_scratch(owner, "_vc_sums", (2, G, C), dev)  # cleared again by vc_bn_finalize
             stat = torch.empty(4, G, C, device=dev, dtype=torch.float32)  # mean, invstd, scale, shift
             if partial is not None:
@@ -848,6 +908,8 @@ class _BatchNormPool(torch.autograd.Function):
             if F_ % G:
                 raise RuntimeError(f"batch_norm_pool: {F_} frames do not split into {G} groups")
             rpg = M // G
+            global _bn_stats_epoch
+            _bn_stats_epoch += 1
             sums = _zero_scratch(owner, "_vc_sums", (2, G, C), dev)
             stat = torch.empty(4, G, C, device=dev, dtype=torch.float32)
             if partial is not None:
