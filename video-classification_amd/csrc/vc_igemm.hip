@@ -521,12 +521,8 @@ constexpr int EPI_NONE = 0, EPI_BN_TAIL = 1, EPI_RESIDUAL = 2, EPI_GELU_BWD = 3,
 // EPI_BN_PRE: the tile is the gradient of relu(bn(y)); `bias` carries the BatchNorm's [4][G][Co] table (mean, invstd,
 // scale, shift per group of `relu` = rows-per-group rows), tail_y = y.  The epilogue zeroes the gradient where
 // y * scale + shift <= 0 and writes the slab sums of dz and dz * y, as EPI_BN_TAIL does from recorded decisions.
-__device__ __forceinline__ float gelu_dev(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
-
-__device__ __forceinline__ float gelu_grad_dev(float x) {  // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
-  const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
-  return cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);
-}
+__device__ __forceinline__ float gelu_dev(float x) { return vc_gelu(x); }
+__device__ __forceinline__ float gelu_grad_dev(float x) { return vc_gelu_grad(x); }
 
 template <int MODE, int WI, int EPI = EPI_NONE, bool HAS_BIAS = true>
 __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[WI][4], int m0, int n0, int wm,

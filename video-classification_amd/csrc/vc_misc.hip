@@ -261,12 +261,8 @@ __global__ void avgpool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx,
 // OP 2: out = relu(a)            OP 3: out = gelu(a)        OP 4: out = a * gelu'(b)
 // OP 5: out = sigmoid(a)
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_grad_f(float x) {
-  const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
-  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
-}
+__device__ __forceinline__ float gelu_f(float x) { return vc_gelu(x); }
+__device__ __forceinline__ float gelu_grad_f(float x) { return vc_gelu_grad(x); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
 
 template <typename T, int OP>
