@@ -72,7 +72,7 @@ def test_hip_path_refuses_cpu_tensors():
 
 def test_only_known_kernels_spill():
     """Kernel resource use is read from the code objects inside the built library (no GPU needed).  A kernel that
-    starts spilling at the 256-register limit loses a large factor silently (round 2: 20-96 bytes of scratch in two
+    starts spilling at the 256-register limit loses a large factor silently (measured: 20-96 bytes of scratch in two
     GEMM epilogue variants cost the Swin step 3 %), so the set of kernels that use scratch memory is pinned: the
     window-attention backward, which holds its bias tables and both accumulator sets in all 512 registers."""
     import sys

@@ -2,7 +2,7 @@
 classes over RCCL): flat parameter/gradient buffers, bucket partition, gradient-ready notifications, the
 overlapped all-reduce and its finish(), initial broadcast.
 
-Correctness criterion (SURVEY multi-GPU row): gradients summed over ranks and scaled by 1/world equal the
+Correctness criterion: gradients summed over ranks and scaled by 1/world equal the
 single-process gradients of the concatenated batch (a BatchNorm-free model, mean cross-entropy)."""
 import os
 import socket
