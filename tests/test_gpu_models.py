@@ -747,3 +747,43 @@ def test_deterministic_mode_other_models(cuda, which):
     for k in a:
         assert torch.isfinite(a[k]).all(), k
         assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.gpu
+def test_train_epoch_replaying_the_step_as_a_graph(cuda):
+    """train_epoch(graph=True): the first batch runs eagerly once and is captured, later batches of that shape replay
+    the hipGraph, the short last batch runs eagerly.  Same losses, accuracy and weights as the eager epoch (ordered
+    sums, so that Adam does not turn the atomics' noise into +-lr), over two epochs with a scheduler step between."""
+    from video_classification_amd import ops, trainer as TR
+    from video_classification_amd.modules import CRNNModel
+    d = G.load("crnn_tiny_step")
+    g = torch.Generator().manual_seed(21)
+    B = d["in/x"].shape[0]
+    batches = [(torch.randn(*d["in/x"].shape, generator=g), torch.randint(0, 101, (B, 1), generator=g)) for _ in range(4)]
+    batches.append((batches[0][0][:2].clone(), batches[0][1][:2].clone()))    # a short last batch
+    ops.set_deterministic(True, workspace_mb=64)
+    try:
+        results = []
+        for graph in (False, True):
+            model = CRNNModel(G.tiny_crnn_config())
+            model.load_state_dict(G.group(d, "p"), strict=True)
+            model.to(cuda).set_compute_dtype(torch.float32)
+            opt = TR.get_optimizer(model, "adam", lr=1e-3, weight_decay=1e-4)
+            sched = TR.get_scheduler(opt, "step", step_size=1, gamma=0.5)
+            crit = TR.FusedCrossEntropyLoss()
+            ops.manual_seed(77)
+            stats = []
+            for epoch in range(2):
+                stats.append(TR.train_epoch(model, batches, crit, opt, cuda, epoch, graph=graph))
+                stats.append(TR.validate_epoch(model, batches[:1], crit, cuda, epoch))
+                sched.step()
+            assert opt.steps == 10
+            assert (getattr(model, "_vc_train_graph", None) is not None) == graph
+            results.append((stats, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}))
+    finally:
+        ops.set_deterministic(False)
+    (se, we), (sg, wg) = results
+    for (le, ae), (lg, ag) in zip(se, sg):
+        assert abs(le - lg) < 1e-4 and ae == ag
+    for k in we:
+        assert (we[k].double() - wg[k].double()).abs().max().item() < 1e-5, k

@@ -35,7 +35,9 @@ class GraphedTrainStep:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):  # real training steps on the example batch
-                self._eager()
+                self.first_loss = self._eager().detach()
+                stats = getattr(criterion, "stats", None) or {}
+                self.first_correct = stats["correct"].clone() if "correct" in stats else None
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         # no collectives inside the capture: the hook only notes in which phase a parameter's gradient is complete

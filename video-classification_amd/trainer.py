@@ -385,22 +385,54 @@ def _run_batch(model, data, target, criterion):
     return output, loss, correct
 
 
-def train_epoch(model, train_loader, criterion, optimizer, device, epoch, use_amp=False, scaler=None, logger=None):
+# VC_TRAIN_GRAPH=1: train_epoch replays the step as a hipGraph by default (its `graph` argument overrides)
+TRAIN_GRAPH = os.environ.get("VC_TRAIN_GRAPH", "0") == "1"
+
+
+def _graphed_batch(model, criterion, optimizer, data, target):
+    """(loss, number of correct predictions) of one training step replayed as a hipGraph, or None when this batch has
+    to run eagerly.  The first batch builds the graph: GraphedTrainStep runs exactly ONE eager step on it -- that
+    batch's training step -- and captures; later batches of the same shape replay; batches of another shape (the
+    short last batch of an epoch) run eagerly."""
+    from .graph import GraphedTrainStep
+    tgt = target.reshape(-1)
+    key = (tuple(data.shape), data.dtype, tuple(tgt.shape))
+    cached = getattr(model, "_vc_train_graph", None)
+    if cached is None:
+        gs = GraphedTrainStep(model, optimizer, criterion, data, tgt, warmup=1)
+        object.__setattr__(model, "_vc_train_graph", (key, gs))
+        return gs.first_loss, gs.first_correct
+    if cached[0] != key:
+        return None
+    loss = cached[1](data, tgt)
+    return loss, criterion.stats["correct"]
+
+
+def train_epoch(model, train_loader, criterion, optimizer, device, epoch, use_amp=False, scaler=None, logger=None,
+                graph=None):
     """Returns (average loss over batches, accuracy %), as the reference's train_epoch.  Loss and accuracy
     are accumulated on the device and read back once per logging interval instead of three times per
     batch.  `use_amp`/`scaler` are accepted for signature compatibility; precision is chosen by the
-    model's compute dtype."""
+    model's compute dtype.  graph=True replays the step (zero-grad, forward, loss, backward, optimizer) as one
+    hipGraph for every batch of the first batch's shape instead of launching ~3000 kernels from Python; it needs the
+    fused criterion and optimizer of this module."""
     model.train()
+    use_graph = (TRAIN_GRAPH if graph is None else bool(graph)) and isinstance(criterion, FusedCrossEntropyLoss) \
+        and isinstance(optimizer, FusedOptimizer)
     total_loss = torch.zeros((), device=device)
     correct = torch.zeros((), device=device, dtype=torch.int64)
     total = 0
     nb = 0
     for batch_idx, (data, target) in enumerate(train_loader):
         data, target = data.to(device, non_blocking=True), target.to(device, non_blocking=True)
-        optimizer.zero_grad()
-        _, loss, ncorrect = _run_batch(model, data, target, criterion)
-        loss.backward()
-        optimizer.step()
+        done = _graphed_batch(model, criterion, optimizer, data, target) if use_graph else None
+        if done is not None:
+            loss, ncorrect = done
+        else:
+            optimizer.zero_grad()
+            _, loss, ncorrect = _run_batch(model, data, target, criterion)
+            loss.backward()
+            optimizer.step()
         total_loss += loss.detach()
         correct += ncorrect.reshape(()).to(torch.int64)
         total += target.size(0)
