@@ -207,3 +207,42 @@ def test_swin_block_stochastic_depth_fused_equals_unfused(cuda):
     assert 0 < (a - x.float().cpu()).abs().amax(dim=(1, 2, 3)).eq(0).sum() == untouched.sum() < F_
     for u, v in zip(res[True], res[False]):
         assert G.max_rel(u, v) < 2e-2
+
+
+def test_swin_rnn_deterministic_mode(cuda):
+    """ops.set_deterministic on the Swin model: with the relative-position-bias gradient folded in a fixed order (inside a
+    block always, across blocks through the workspace) and LayerNorm's parameter gradients summed in order, two steps
+    from the same state repeat bit for bit."""
+    from video_classification_amd import ops, swin as S
+    from video_classification_amd.modules import DecoderRNN, SwinTransformerRNNModel
+
+    def run():
+        torch.manual_seed(5)
+        enc = S.SwinTransformerEncoder(64, 48, 0.0, 32, swin_kwargs=dict(img=56, patch=4, dim=32, depths=(2, 2),
+                                                                          heads=(1, 2), ws=7, drop_path_rate=0.1))
+        dec = DecoderRNN(32, 2, 24, 16, 0.0, 9)
+        model = SwinTransformerRNNModel(enc, dec).to(cuda)
+        model.set_compute_dtype(torch.bfloat16)
+        model.train()
+        ops.manual_seed(99)
+        g = torch.Generator().manual_seed(6)
+        x = torch.randn(6, 3, 3, 56, 56, generator=g).to(cuda)
+        y = torch.randint(0, 9, (6,), generator=g).to(cuda)
+        loss = ops.cross_entropy(model(x), y)
+        loss.backward()
+        torch.cuda.synchronize()
+        res = {"loss": loss.detach().float().cpu().reshape(-1)}
+        for k, p in model.named_parameters():
+            if p.grad is not None:
+                res["grad." + k] = p.grad.detach().float().cpu()
+        return res
+
+    ops.set_deterministic(True, workspace_mb=64)
+    try:
+        a, b = run(), run()
+    finally:
+        ops.set_deterministic(False)
+    assert any("relative_position_bias_table" in k for k in a)
+    for k in a:
+        assert torch.isfinite(a[k]).all(), k
+        assert torch.equal(a[k], b[k]), k

@@ -553,7 +553,8 @@ __global__ __launch_bounds__(64 * AW, 1) __attribute__((amdgpu_waves_per_eu(1, 1
                                                                            const float* __restrict__ bias_table,
                                                                            bf16* __restrict__ dqkv,
                                                                            float* __restrict__ dbias_table,
-                                                                           float scale, int windows_total, int wpw) {
+                                                                           float scale, int windows_total, int wpw,
+                                                                           size_t bin_slots) {
   __shared__ __attribute__((aligned(16))) bf16 sT[AW][4][TS];   // q, k, v, dO tiles per wave
   __shared__ float sBias[AW][176];
   __shared__ float sBin[176];
@@ -796,7 +797,7 @@ __global__ __launch_bounds__(64 * AW, 1) __attribute__((amdgpu_waves_per_eu(1, 1
     }
   }
   __syncthreads();
-  if (dbias_table) {
+  if (dbias_table && bin_slots == 0) {
     // fold the lane-owned (i, j) sums onto the (2ws-1)^2 relative-position bins in LDS, then one global atomic
     // per bin and block
 #pragma unroll
@@ -810,6 +811,31 @@ __global__ __launch_bounds__(64 * AW, 1) __attribute__((amdgpu_waves_per_eu(1, 1
         }
     __syncthreads();
     if ((int)threadIdx.x < nb) atomicAdd(dbias_table + threadIdx.x * g.heads + head, sBin[threadIdx.x]);
+  } else if (dbias_table) {
+    // Deterministic mode: the same fold in a fixed order.  Every wave parks its 64 x 64 matrix in LDS (the operand
+    // tiles are free now: exactly 4 x 16 KiB), then thread t adds up bin t -- the waves in order, the (query, key)
+    // pairs of that offset in order -- into the block's own copy (blockIdx.x) of the table; the copies are added in
+    // block order by the caller.
+    float* mat = reinterpret_cast<float*>(&sT[0][0][0]) + wave * 4096;
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj)
+        *reinterpret_cast<f32x4*>(mat + (16 * ti + l15) * 64 + 16 * tj + 4 * gq) =
+            f32x4{dbacc[ti][tj][0], dbacc[ti][tj][1], dbacc[ti][tj][2], dbacc[ti][tj][3]};
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < nb) {
+      const int span = 2 * g.ws - 1;
+      const int di = t / span - (g.ws - 1), dj = t % span - (g.ws - 1);  // query row / column minus key row / column
+      const float* all = reinterpret_cast<const float*>(&sT[0][0][0]);
+      float sum = 0.f;
+      for (int w = 0; w < AW; ++w)
+        for (int ki = max(0, -di); ki < min(g.ws, g.ws - di); ++ki)
+          for (int kj = max(0, -dj); kj < min(g.ws, g.ws - dj); ++kj)
+            sum += all[w * 4096 + ((ki + di) * g.ws + kj + dj) * 64 + ki * g.ws + kj];
+      dbias_table[(size_t)blockIdx.x * bin_slots + t * g.heads + head] = sum;  // the only writer of this entry
+    }
   }
 }
 
@@ -861,8 +887,21 @@ int vc_window_attn_bwd(int dtype, const void* qkv, const void* dout, const float
     int wpw = 1;  // windows per wave: enough blocks to fill the chip, few enough that the bias atomics stay cheap
     while ((int64_t)ceil_div(windows, AW * wpw) * heads > 1024) wpw *= 2;
     dim3 mgrid(ceil_div(windows, AW * wpw), heads);
+    // deterministic mode: a copy of the bias-gradient table per block column, added in order afterwards
+    const size_t nbins = (size_t)(2 * ws - 1) * (2 * ws - 1) * heads;
+    const bool ordered = vc_deterministic() && dbias_table;
+    float* table = dbias_table;
+    if (ordered) {
+      table = vc_det_workspace(nbins * mgrid.x, stream, "vc_window_attn_bwd");
+      if (!table) return VC_ERR_ARG;
+    }
     hipLaunchKernelGGL(window_attn_bwd_mfma_kernel, mgrid, dim3(64 * AW), 0, stream, g, (const bf16*)qkv,
-                       (const bf16*)dout, bias_table, (bf16*)dqkv, dbias_table, scale, windows, wpw);
+                       (const bf16*)dout, bias_table, (bf16*)dqkv, table, scale, windows, wpw,
+                       ordered ? nbins : (size_t)0);
+    if (ordered) {
+      VC_LAUNCH_CHECK("vc_window_attn_bwd");
+      return vc_det_reduce(dbias_table, table, nbins, (int)mgrid.x, stream);
+    }
   }
   else if (dtype == VC_F32)
     hipLaunchKernelGGL((window_attn_bwd_kernel<float>), grid, dim3(64), 0, stream, g, (const float*)qkv,
