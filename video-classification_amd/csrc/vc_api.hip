@@ -20,13 +20,35 @@ int current_device() {
   return dev;
 }
 
-// out[i] += ws[0][i] + ws[1][i] + ... + ws[slots - 1][i], added in that order
-__global__ void det_reduce_kernel(float* __restrict__ out, const float* __restrict__ ws, size_t n, int slots) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// out[i] += the sum over the slots of ws[slot][i], in an order that depends on (n, slots) only: the slots are cut
+// into 8 equal runs, a thread adds one run front to back (four loads in flight), and the 8 run sums of an element are
+// added first to last.  256 threads = 32 elements x 8 runs.
+__global__ __launch_bounds__(256) void det_reduce_kernel(float* __restrict__ out, const float* __restrict__ ws, size_t n,
+                                                         int slots) {
+  __shared__ float part[8][32];
+  const int e = threadIdx.x & 31, run = threadIdx.x >> 5;
+  const size_t i = (size_t)blockIdx.x * 32 + e;
+  const int per = (slots + 7) / 8;
+  const int s0 = run * per, s1 = min(slots, s0 + per);
   float a = 0.f;
-  for (int s = 0; s < slots; ++s) a += ws[(size_t)s * n + i];
-  out[i] += a;
+  if (i < n) {
+    int s = s0;
+    for (; s + 3 < s1; s += 4) {
+      const float v0 = ws[(size_t)s * n + i], v1 = ws[(size_t)(s + 1) * n + i], v2 = ws[(size_t)(s + 2) * n + i],
+                  v3 = ws[(size_t)(s + 3) * n + i];
+      a = ((a + v0) + v1) + v2;
+      a += v3;
+    }
+    for (; s < s1; ++s) a += ws[(size_t)s * n + i];
+  }
+  part[run][e] = a;
+  __syncthreads();
+  if (run == 0 && i < n) {
+    float t = part[0][e];
+#pragma unroll
+    for (int r = 1; r < 8; ++r) t += part[r][e];
+    out[i] += t;
+  }
 }
 }  // namespace
 
@@ -52,7 +74,7 @@ float* vc_det_workspace(size_t floats, hipStream_t stream, const char* who) {
 }
 
 int vc_det_reduce(float* out, const float* ws, size_t n, int slots, hipStream_t stream) {
-  hipLaunchKernelGGL(det_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, out, ws, n, slots);
+  hipLaunchKernelGGL(det_reduce_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, stream, out, ws, n, slots);
   VC_LAUNCH_CHECK("vc_det_reduce");
   return VC_OK;
 }

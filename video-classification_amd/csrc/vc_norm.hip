@@ -727,22 +727,41 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
     }
   }
   if (slot_stride) {
-    for (int turn = 0; turn < RPB; ++turn) {  // row group `turn` adds, the others wait: a fixed order
-      if (rsl == turn) {
+    // every row group parks its sums in its own [2][C] slice (the launch reserves RPB of them), then thread i adds
+    // entry i of the slices in row-group order
+    float* mine = lds + (size_t)rsl * 2 * C;
+    if (rsl > 0) {
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-          const int cc = sub + LPR * k;
-          if (cc < C8) {
+      for (int k = 0; k < NCH; ++k) {
+        const int cc = sub + LPR * k;
+        if (cc < C8) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-              lds[cc * 8 + i] += pg[k][i];
-              lds[C + cc * 8 + i] += pb[k][i];
-            }
+          for (int i = 0; i < 8; ++i) {
+            mine[cc * 8 + i] = pg[k][i];
+            mine[C + cc * 8 + i] = pb[k][i];
           }
         }
       }
-      __syncthreads();
+    } else {
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) {
+        const int cc = sub + LPR * k;
+        if (cc < C8) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            lds[cc * 8 + i] = pg[k][i];
+            lds[C + cc * 8 + i] = pb[k][i];
+          }
+        }
+      }
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+      float t = lds[i];
+      for (int r = 1; r < RPB; ++r) t += lds[(size_t)r * 2 * C + i];
+      lds[i] = t;
+    }
+    __syncthreads();
   } else {
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
@@ -1120,9 +1139,10 @@ int vc_layernorm_bwd_add(int dtype, const void* x, const void* dout, const float
   int rows_per_block = 64;
   while (ceil_div(M, rows_per_block) > 1024) rows_per_block *= 2;
   dim3 grid(ceil_div(M, rows_per_block));
-  const size_t lds = 2 * (size_t)C * sizeof(float);
-  // deterministic mode: a copy of dgamma / dbeta per block, added in block order afterwards
+  // deterministic mode: a copy of dgamma / dbeta per block, added in block order afterwards (and one [2][C] slice of
+  // LDS per row group of a block: 256 / lpr of them, at most 24 KiB)
   const bool ordered = vc_deterministic();
+  const size_t lds = 2 * (size_t)C * sizeof(float) * (ordered ? 256 / lpr : 1);
   float* const dg_user = dgamma;
   float* const db_user = dbeta;
   size_t slot_stride = 0;

@@ -61,7 +61,7 @@ _det_workspaces = {}
 def set_deterministic(on=True, workspace_mb=256):
     """Bit-for-bit repeatable steps (the counterpart of torch.backends.cudnn.deterministic = True): sums that the kernels
     otherwise combine with fp32 atomics are added in a fixed order, through a workspace of `workspace_mb` MiB that is
-    registered with the library for the current device.  Call once per device a model runs on.  About 10 % slower."""
+    registered with the library for the current device.  Call once per device a model runs on.  About 5 % slower."""
     global WGRAD_STREAM
     if not on:
         L.call("vc_set_deterministic", 0, L.ptr(None), L.i64(0))
