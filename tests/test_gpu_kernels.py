@@ -410,3 +410,20 @@ def test_layernorm_gradients_in_deterministic_mode(cuda, M, C):
         assert torch.equal(u, v)
     for u, v in zip(a, base):
         assert G.max_rel(u.float().cpu(), v.float().cpu()) < 1e-4
+
+
+def test_batchnorm_single_value_per_channel_raises(cuda):
+    """Training-mode BatchNorm over one value per channel (a batch of one clip through the BatchNorm1d heads) raises as
+    torch's does, instead of writing an infinite running variance; eval mode takes it."""
+    from video_classification_amd import ops
+    bn = nn.BatchNorm1d(16).to(cuda)
+    x = torch.randn(3, 16, device=cuda).bfloat16()
+    with pytest.raises(ValueError, match="more than 1 value per channel"):
+        ops.batch_norm(x, bn, 3)          # three groups (time steps) of one frame each
+    ref = nn.BatchNorm1d(16)
+    with pytest.raises(ValueError, match="more than 1 value per channel"):
+        ref(torch.randn(1, 16))
+    assert torch.isfinite(bn.running_var).all()
+    bn.eval()
+    with torch.no_grad():
+        assert torch.isfinite(ops.batch_norm(x, bn, 3).float()).all()

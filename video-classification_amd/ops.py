@@ -763,6 +763,8 @@ class _BatchNorm(torch.autograd.Function):
             if M % G:
                 raise RuntimeError(f"batch_norm: {M} rows do not split into {G} groups")
             rpg = M // G
+            if rpg == 1:  # torch's BatchNorm raises the same way (a single frame through the BatchNorm1d heads)
+                raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(y.shape)}")
             global _bn_stats_epoch
             _bn_stats_epoch += 1  # running statistics are rewritten through raw pointers: folded weights go stale
             sums = _zero_scratch(owner, "_vc_sums", (2, G, C), dev)  # cleared again by vc_bn_finalize
