@@ -730,28 +730,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
     // every row group parks its sums in its own [2][C] slice (the launch reserves RPB of them), then thread i adds
     // entry i of the slices in row-group order
     float* mine = lds + (size_t)rsl * 2 * C;
-    if (rsl > 0) {
 #pragma unroll
-      for (int k = 0; k < NCH; ++k) {
-        const int cc = sub + LPR * k;
-        if (cc < C8) {
+    for (int k = 0; k < NCH; ++k) {
+      const int cc = sub + LPR * k;
+      if (cc < C8) {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            mine[cc * 8 + i] = pg[k][i];
-            mine[C + cc * 8 + i] = pb[k][i];
-          }
-        }
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < NCH; ++k) {
-        const int cc = sub + LPR * k;
-        if (cc < C8) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            lds[cc * 8 + i] = pg[k][i];
-            lds[C + cc * 8 + i] = pb[k][i];
-          }
+        for (int i = 0; i < 8; ++i) {
+          mine[cc * 8 + i] = pg[k][i];
+          mine[C + cc * 8 + i] = pb[k][i];
         }
       }
     }
