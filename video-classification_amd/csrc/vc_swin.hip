@@ -543,6 +543,20 @@ __global__ __launch_bounds__(64 * AW) void window_attn_fwd_mfma_kernel(SwinGeom 
   }
 }
 
+__device__ __attribute__((aligned(64))) const uint32_t swin_zero_src[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+typedef __attribute__((address_space(1))) const void* swin_gptr_t;
+typedef __attribute__((address_space(3))) void* swin_lptr_t;
+// one wave-instruction of LDS-DMA: lane l moves 16 bytes from its own global address to lds_wave_base + 16 l
+__device__ __forceinline__ void glds16_swin(const void* gsrc, bf16* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((swin_gptr_t)gsrc, (swin_lptr_t)lds_wave_base, 16, 0, 0);
+}
+// Orders a wave's own LDS traffic for the compiler.  The LDS serves one wave's instructions in issue order, so what the
+// wave wrote (or what its LDS-DMA requests delivered before a vmcnt wait) is what its later reads return.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 // grid = (window chunks, heads); each wave walks `wpw` windows of one head.  Everything that does not depend on
 // the window is hoisted into registers before the walk: the relative-position bias (plus the -inf of the padded
 // keys) of the 64 (i, j) elements a lane owns in either orientation, and the bias-gradient accumulator of the
@@ -555,11 +569,14 @@ __global__ __launch_bounds__(64 * AW, 1) __attribute__((amdgpu_waves_per_eu(1, 1
                                                                            float* __restrict__ dbias_table,
                                                                            float scale, int windows_total, int wpw,
                                                                            size_t bin_slots) {
-  __shared__ __attribute__((aligned(16))) bf16 sT[AW][4][TS];   // q, k, v, dO tiles per wave
+  // q, k, v, dO tiles per wave, TWICE: the tiles of the wave's next window stream in (LDS-DMA) while the current
+  // window is multiplied.  128 KiB of the 160: one block per CU, which the 512 registers per wave allow anyway.
+  __shared__ __attribute__((aligned(1024))) bf16 sT2[AW][2][4][TS];
   __shared__ float sBias[AW][176];
   __shared__ float sBin[176];
-  __shared__ int sReg[AW][64];
-  __shared__ int sTok[AW][64];
+  __shared__ f32x4 sBT2[16][64];   // bias (+ -inf of the padded keys) of the elements a lane owns in orientation 2
+  __shared__ int sReg2[AW][2][64];
+  __shared__ int sTok2[AW][2][64];
   __shared__ int sRC[64];
   __shared__ float sMax[AW][64], sInv[AW][64], sDot[AW][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -575,7 +592,7 @@ __global__ __launch_bounds__(64 * AW, 1) __attribute__((amdgpu_waves_per_eu(1, 1
 
   // orientation 1: element (ti, tj, r) = (query i = 16ti + l15, key j = 16tj + 4gq + r)
   // orientation 2: element (ti, r, tj) = (query i = 16ti + 4gq + r, key j = 16tj + l15)
-  float bt1[4][4][4], bt2[4][4][4], dbacc[4][4][4];
+  float bt1[4][4][4], dbacc[4][4][4];
 #pragma unroll
   for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
@@ -587,56 +604,84 @@ __global__ __launch_bounds__(64 * AW, 1) __attribute__((amdgpu_waves_per_eu(1, 1
           const int ic = i < N ? i : N - 1;
           bt1[ti][tj][r] = j < N ? sBias[wave][sRC[ic] - sRC[j] + off] : -INFINITY;
         }
-        {
+        if (ti == wave) {  // the second orientation's table is the same for every wave: one copy in LDS, a row tile each
           const int i = 16 * ti + 4 * gq + r, j = 16 * tj + l15;
           const int ic = i < N ? i : N - 1;
-          bt2[ti][r][tj] = j < N ? sBias[wave][sRC[ic] - sRC[j] + off] : -INFINITY;
+          sBT2[ti * 4 + r][lane][tj] = j < N ? sBias[wave][sRC[ic] - sRC[j] + off] : -INFINITY;
         }
         dbacc[ti][tj][r] = 0.f;
       }
+  __syncthreads();
 
   const int w_first = (blockIdx.x * AW + wave) * wpw;
-  for (int it = 0; it < wpw; ++it) {
+  const bool tvalid = lane < N;
+  // tokens and shift-mask regions of window `it` into table set `buf`, its four operand tiles requested into tile set
+  // `buf` (16 LDS-DMA instructions per lane: lane l of instruction k fetches 16 bytes of token 16k + l/4)
+  auto request_window = [&](int it, int buf) {
     int win = w_first + it;
-    const bool uvalid = win < windows_total;
-    if (!uvalid) win = windows_total - 1;
+    if (win >= windows_total) win = windows_total - 1;
     int u = win;
     const int ww = u % g.nww;
     u /= g.nww;
     const int wh = u % g.nwh;
     const int b = u / g.nwh;
     int tok = 0, reg = 0;
-    const bool tvalid = lane < N;
     if (tvalid) {
       int ph, pw;
       tok = token_of(g, b, wh, ww, lane, ph, pw);
       reg = region_of(ph, g.H, g.ws, g.shift) * 3 + region_of(pw, g.W, g.ws, g.shift);
     }
-    __syncthreads();  // every wave has finished reading the previous window's LDS
-    sReg[wave][lane] = reg;
-    sTok[wave][lane] = tvalid ? tok : -1;
+    sReg2[wave][buf][lane] = reg;
+    sTok2[wave][buf][lane] = tvalid ? tok : -1;
 #pragma unroll
-    for (int w3 = 0; w3 < 3; ++w3)
-      stage_tile(sT[wave][w3], qkv, (size_t)3 * g.C, w3 * g.C + head * HD, tok, tvalid, lane);
-    stage_tile(sT[wave][3], dout, (size_t)g.C, head * HD, tok, tvalid, lane);
-    __syncthreads();
-    const bf16* tQ = sT[wave][0];
-    const bf16* tK = sT[wave][1];
-    const bf16* tV = sT[wave][2];
-    const bf16* tD = sT[wave][3];
+    for (int k = 0; k < 4; ++k) {
+      const int t = 16 * k + (lane >> 2);
+      const int tk = __shfl(tok, t, 64);
+      const bool ok = t < N;
+      const bf16* zero = reinterpret_cast<const bf16*>(swin_zero_src);
+#pragma unroll
+      for (int w3 = 0; w3 < 3; ++w3)
+        glds16_swin(ok ? qkv + (size_t)tk * 3 * g.C + w3 * g.C + head * HD + 8 * (lane & 3) : zero,
+                    sT2[wave][buf][w3] + k * 16 * HD);
+      glds16_swin(ok ? dout + (size_t)tk * g.C + head * HD + 8 * (lane & 3) : zero, sT2[wave][buf][3] + k * 16 * HD);
+    }
+  };
+  request_window(0, 0);
+  bool stored = false;  // the previous window wrote its gradients (a window beyond the last one does not)
+  for (int it = 0; it < wpw; ++it) {
+    const int cur = it & 1;
+    const bool uvalid = w_first + it < windows_total;
+    // In issue order the wave has outstanding: [this window's 16 tile requests] [the previous window's 24 gradient
+    // stores].  vmcnt retires in order, so "at most 24 outstanding" means the tiles have landed WITHOUT waiting for
+    // the stores' acknowledgements (several microseconds under load); they get the whole window to arrive, because
+    // the next wait that covers them is the next window's.  Register spills only add instructions behind the
+    // requests, which makes the bound conservative.
+    if (stored) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wave_lds_fence();
+    // the next window's tiles go into the other set, whose last reader was the window before this one (the LDS serves
+    // a wave's instructions in order, and every tile and table here is private to the wave: no workgroup barrier)
+    if (it + 1 < wpw) request_window(it + 1, cur ^ 1);
+    stored = uvalid;
+    const int* sRegW = sReg2[wave][cur];
+    const int* sTokW = sTok2[wave][cur];
+    const bf16* tQ = sT2[wave][cur][0];
+    const bf16* tK = sT2[wave][cur][1];
+    const bf16* tV = sT2[wave][cur][2];
+    const bf16* tD = sT2[wave][cur][3];
     // shift-mask regions of this window for the elements the lane owns (padded tokens take token N-1's)
     int ri1[4], rj1[4][4], ri2[4][4], rj2[4];
     if (g.shift) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int i1 = 16 * t + l15;
-        ri1[t] = sReg[wave][i1 < N ? i1 : N - 1];
+        ri1[t] = sRegW[i1 < N ? i1 : N - 1];
         const int j2 = 16 * t + l15;
-        rj2[t] = sReg[wave][j2 < N ? j2 : N - 1];
+        rj2[t] = sRegW[j2 < N ? j2 : N - 1];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int x = 16 * t + 4 * gq + r;
-          const int v = sReg[wave][x < N ? x : N - 1];
+          const int v = sRegW[x < N ? x : N - 1];
           rj1[t][r] = v;
           ri2[t][r] = v;
         }
@@ -721,7 +766,7 @@ __global__ __launch_bounds__(64 * AW, 1) __attribute__((amdgpu_waves_per_eu(1, 1
       for (int ti = 0; ti < 4; ++ti) {
         const int i = 16 * ti + l15;
         if (i >= N) continue;
-        bf16* drow = dqkv + (size_t)sTok[wave][i] * 3 * g.C + head * HD;
+        bf16* drow = dqkv + (size_t)sTokW[i] * 3 * g.C + head * HD;
 #pragma unroll
         for (int te = 0; te < 2; ++te) {
           bf16x4 v;
@@ -731,7 +776,7 @@ __global__ __launch_bounds__(64 * AW, 1) __attribute__((amdgpu_waves_per_eu(1, 1
         }
       }
     }
-    __syncthreads();  // sMax / sInv / sDot written by the lanes that own i are visible to every lane
+    wave_lds_fence();  // sMax / sInv / sDot written by the lanes that own i are read by every lane of the wave
     // ---- orientation 2: rows i, columns j (lane <-> key j); two row tiles (one k-step) at a time ---------
     f32x4 dv[2][4], dk[2][4];
 #pragma unroll
@@ -755,9 +800,10 @@ __global__ __launch_bounds__(64 * AW, 1) __attribute__((amdgpu_waves_per_eu(1, 1
           const int i = 16 * ti + 4 * gq + r;
           const float mx = sMax[wave][i], dot = sDot[wave][i];
           const float inv = (i < N) ? sInv[wave][i] : 0.f;  // padded queries contribute nothing
+          const f32x4 b2 = sBT2[ti * 4 + r][lane];
 #pragma unroll
           for (int tj = 0; tj < 4; ++tj) {
-            float sc = fmaf(st[h][tj][r], scale, bt2[ti][r][tj]);
+            float sc = fmaf(st[h][tj][r], scale, b2[tj]);
             if (g.shift && ri2[ti][r] != rj2[tj]) sc -= 100.f;
             const float p = __expf(sc - mx) * inv;  // P[i][j]
             st[h][tj][r] = p;
@@ -781,7 +827,7 @@ __global__ __launch_bounds__(64 * AW, 1) __attribute__((amdgpu_waves_per_eu(1, 1
       for (int tj = 0; tj < 4; ++tj) {
         const int j = 16 * tj + l15;
         if (j >= N) continue;
-        bf16* drow = dqkv + (size_t)sTok[wave][j] * 3 * g.C + head * HD;
+        bf16* drow = dqkv + (size_t)sTokW[j] * 3 * g.C + head * HD;
 #pragma unroll
         for (int te = 0; te < 2; ++te) {
           bf16x4 vk, vv;
@@ -816,7 +862,7 @@ __global__ __launch_bounds__(64 * AW, 1) __attribute__((amdgpu_waves_per_eu(1, 1
     // tiles are free now: exactly 4 x 16 KiB), then thread t adds up bin t -- the waves in order, the (query, key)
     // pairs of that offset in order -- into the block's own copy (blockIdx.x) of the table; the copies are added in
     // block order by the caller.
-    float* mat = reinterpret_cast<float*>(&sT[0][0][0]) + wave * 4096;
+    float* mat = reinterpret_cast<float*>(&sT2[0][0][0][0]) + wave * 4096;
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
@@ -828,7 +874,7 @@ __global__ __launch_bounds__(64 * AW, 1) __attribute__((amdgpu_waves_per_eu(1, 1
     if (t < nb) {
       const int span = 2 * g.ws - 1;
       const int di = t / span - (g.ws - 1), dj = t % span - (g.ws - 1);  // query row / column minus key row / column
-      const float* all = reinterpret_cast<const float*>(&sT[0][0][0]);
+      const float* all = reinterpret_cast<const float*>(&sT2[0][0][0][0]);
       float sum = 0.f;
       for (int w = 0; w < AW; ++w)
         for (int ki = max(0, -di); ki < min(g.ws, g.ws - di); ++ki)
