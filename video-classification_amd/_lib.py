@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvc_hip.so")
+LIB_PATH = os.environ.get("VC_LIB_PATH") or os.path.join(_HERE, "libvc_hip.so")  # VC_LIB_PATH: an experimental build
 
 VC_F32 = 0
 VC_BF16 = 1

@@ -524,6 +524,19 @@ constexpr int EPI_NONE = 0, EPI_BN_TAIL = 1, EPI_RESIDUAL = 2, EPI_GELU_BWD = 3,
 __device__ __forceinline__ float gelu_dev(float x) { return vc_gelu(x); }
 __device__ __forceinline__ float gelu_grad_dev(float x) { return vc_gelu_grad(x); }
 
+// 16-byte accesses of the output tile and of an epilogue's side tensor
+#ifndef VC_EPI_NT
+#define VC_EPI_NT 0
+#endif
+__device__ __forceinline__ void epi_store8(bf16* p, const bf16x8& v) {
+  if (VC_EPI_NT & 1) __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(p));
+  else *reinterpret_cast<bf16x8*>(p) = v;
+}
+__device__ __forceinline__ bf16x8 epi_load8(const bf16* p) {
+  if (VC_EPI_NT & 2) return __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p));
+  return *reinterpret_cast<const bf16x8*>(p);
+}
+
 template <int MODE, int WI, int EPI = EPI_NONE, bool HAS_BIAS = true>
 __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[WI][4], int m0, int n0, int wm,
                                                 int wn, int lane, const float* __restrict__ bias,
@@ -592,10 +605,10 @@ __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[
     const bool live = m < g.M && co < g.Co;
     orow[it] = live ? out + (size_t)(MODE == 2 ? phase_out_pixel(g, m) : m) * g.ldc + co : nullptr;
     oldv[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    if (beta && live && vec) oldv[it] = *reinterpret_cast<const bf16x8*>(orow[it]);
+    if (beta && live && vec) oldv[it] = epi_load8(orow[it]);
     if (SIDE_IN) {
       tyv[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-      if (live) tyv[it] = *reinterpret_cast<const bf16x8*>(tail_y + (size_t)m * g.Co + co);
+      if (live) tyv[it] = epi_load8(tail_y + (size_t)m * g.Co + co);
     }
     if (TAIL) {
       tbits[it] = 0;
@@ -626,7 +639,7 @@ __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[
         ps[e] += dz;
         pq[e] = fmaf(dz, (float)tyv[it][e], pq[e]);
       }
-      if (op) *reinterpret_cast<bf16x8*>(op) = v;
+      if (op) epi_store8(op, v);
     } else if (PRE) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -638,14 +651,14 @@ __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[
           pq[e] = fmaf(dz, yy, pq[e]);
         }
       }
-      if (op) *reinterpret_cast<bf16x8*>(op) = v;
+      if (op) epi_store8(op, v);
     } else if (EPI == EPI_GELU_DUAL) {  // host guarantees vec and beta == 0
       if (op) {
         bf16x8 gv;
 #pragma unroll
         for (int e = 0; e < 8; ++e) gv[e] = (bf16)gelu_dev((float)v[e]);
-        *reinterpret_cast<bf16x8*>(op) = v;
-        *reinterpret_cast<bf16x8*>(const_cast<bf16*>(tail_y) + (size_t)m * g.Co + co) = gv;
+        epi_store8(op, v);
+        epi_store8(const_cast<bf16*>(tail_y) + (size_t)m * g.Co + co, gv);
       }
     } else if (EPI == EPI_RESIDUAL || EPI == EPI_GELU_BWD) {  // host guarantees vec
       if (op) {
@@ -666,7 +679,7 @@ __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[
           }
           v[e] = (bf16)t;
         }
-        *reinterpret_cast<bf16x8*>(op) = v;
+        epi_store8(op, v);
       }
     } else if (op) {
       if (vec) {
@@ -678,7 +691,7 @@ __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[
             v[e] = (bf16)t;
           }
         }
-        *reinterpret_cast<bf16x8*>(op) = v;
+        epi_store8(op, v);
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e)

@@ -15,13 +15,50 @@ namespace {
 
 constexpr int NTHR = 256;
 
+// Cache policy of the bf16 streaming passes, two bits per kernel (1 = non-temporal loads, 2 = non-temporal stores):
+// bits 0-1 forward apply, bits 2-3 backward apply, bits 4-5 backward reduce.  The apply passes touch every byte once;
+// streaming them past L2 leaves the GEMM kernels on either side their operands and fewer dirty lines to write back.
+// Measured on the ResNet-50 CRNN step (32 clips): 47.98 ms with the default policy everywhere, 46.32 ms with both
+// apply passes non-temporal (forward alone -0.7 ms, backward alone -1.1 ms), no change from the reduce, and less gain
+// when tensors below 100 / 300 MB are left cached (46.45 / 46.94 ms).  VC_BN_NT overrides the setting (0 = default
+// policy everywhere), VC_BN_NT_MIN_MB leaves smaller tensors cached.
+inline int bn_nt_policy(size_t tensor_bytes) {
+  static const int v = [] {
+    const char* e = getenv("VC_BN_NT");
+    return e ? atoi(e) : 15;
+  }();
+  static const size_t min_bytes = [] {
+    const char* e = getenv("VC_BN_NT_MIN_MB");
+    return (size_t)(e ? atoi(e) : 0) << 20;
+  }();
+  return tensor_bytes >= min_bytes ? v : 0;
+}
+
+// Streaming forms of load8 / store8 (non-temporal: the line is not kept in L2 behind the access).  The apply passes
+// touch every byte exactly once.
+__device__ __forceinline__ F8 load8_nt(const bf16* p) {
+  F8 r;
+  const bf16x8 a = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = (float)a[i];
+  return r;
+}
+__device__ __forceinline__ F8 load8_nt(const float* p) { return load8(p); }
+__device__ __forceinline__ void store8_nt(bf16* p, const F8& r) {
+  bf16x8 a;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = (bf16)r.v[i];
+  __builtin_nontemporal_store(a, reinterpret_cast<bf16x8*>(p));
+}
+__device__ __forceinline__ void store8_nt(float* p, const F8& r) { store8(p, r); }
+
 // per-(group, channel) sums of v1 and v2 over the rows of a group
 // MODE 0: v1 = y,  v2 = y*y                       (forward statistics)
 // MODE 1: v1 = dz, v2 = dz * xhat                 (backward reductions), dz = dout * (act > 0 if relu)
 // WRITE_DZ (MODE 1): the ReLU decisions come from the bit mask `bits` ([row][C/8] bytes, bit i = channel 8*cc + i
 // was positive; written by bn_apply_kernel) and dz is also written back over dout (dz_out aliases dout, so neither
 // is __restrict__): the masked gradient is then both the shortcut's gradient and the apply pass's input.
-template <typename T, int MODE, bool WRITE_DZ = false>
+template <typename T, int MODE, bool WRITE_DZ = false, int NT = 0>
 __global__ void bn_reduce_kernel(const T* __restrict__ y, const T* dout, const T* __restrict__ act,
                                  const float* __restrict__ mean, const float* __restrict__ invstd,
                                  const float* __restrict__ scale, const float* __restrict__ shift,
@@ -30,6 +67,11 @@ __global__ void bn_reduce_kernel(const T* __restrict__ y, const T* dout, const T
                                  size_t slot_stride = 0) {
   // slot_stride != 0 (deterministic mode): block x of a group adds into its own copy x of the [G][C] tables
   __shared__ float red[2][NTHR][8];
+  auto ld = [](const T* p) { return (NT & 1) ? load8_nt(p) : load8(p); };
+  auto st = [](T* p, const F8& v) {
+    if (NT & 2) store8_nt(p, v);
+    else store8(p, v);
+  };
   const int C8 = C >> 3;
   const int lanesC = C8 < NTHR ? C8 : NTHR;
   const int RL = NTHR / lanesC;
@@ -61,7 +103,7 @@ __global__ void bn_reduce_kernel(const T* __restrict__ y, const T* dout, const T
           const size_t off = ((size_t)g * rpg + r) * C + cc * 8;
           F8 yv[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) yv[u] = load8(y + off + (size_t)u * RL * C);
+          for (int u = 0; u < 4; ++u) yv[u] = ld(y + off + (size_t)u * RL * C);
 #pragma unroll
           for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -76,8 +118,8 @@ __global__ void bn_reduce_kernel(const T* __restrict__ y, const T* dout, const T
           F8 yv[2], dv[2], av[2];
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
-            yv[u] = load8(y + off + (size_t)u * RL * C);
-            dv[u] = load8(dout + off + (size_t)u * RL * C);
+            yv[u] = ld(y + off + (size_t)u * RL * C);
+            dv[u] = ld(dout + off + (size_t)u * RL * C);
           }
           if (WRITE_DZ) {
 #pragma unroll
@@ -88,7 +130,7 @@ __global__ void bn_reduce_kernel(const T* __restrict__ y, const T* dout, const T
             }
           } else if (relu && act) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) av[u] = load8(act + off + (size_t)u * RL * C);
+            for (int u = 0; u < 2; ++u) av[u] = ld(act + off + (size_t)u * RL * C);
           }
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
@@ -99,7 +141,7 @@ __global__ void bn_reduce_kernel(const T* __restrict__ y, const T* dout, const T
 #pragma unroll
               for (int i = 0; i < 8; ++i) dv[u].v[i] = fmaf(yv[u].v[i], sc[i], sh[i]) > 0.f ? dv[u].v[i] : 0.f;
             }
-            if (WRITE_DZ) store8(dz_out + off + (size_t)u * RL * C, dv[u]);
+            if (WRITE_DZ) st(dz_out + off + (size_t)u * RL * C, dv[u]);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
               a1[i] += dv[u].v[i];
@@ -110,7 +152,7 @@ __global__ void bn_reduce_kernel(const T* __restrict__ y, const T* dout, const T
       }
       for (; r < r_end; r += RL) {
         const size_t off = ((size_t)g * rpg + r) * C + cc * 8;
-        const F8 yv = load8(y + off);
+        const F8 yv = ld(y + off);
         if (MODE == 0) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
@@ -118,14 +160,14 @@ __global__ void bn_reduce_kernel(const T* __restrict__ y, const T* dout, const T
             a2[i] = fmaf(yv.v[i], yv.v[i], a2[i]);
           }
         } else {
-          F8 dv = load8(dout + off);
+          F8 dv = ld(dout + off);
           if (WRITE_DZ) {
             const unsigned mb = bits[((size_t)g * rpg + r) * C8 + cc];
 #pragma unroll
             for (int i = 0; i < 8; ++i) dv.v[i] = (mb >> i) & 1 ? dv.v[i] : 0.f;
           } else if (relu) {
             if (act) {  // the activation had a residual added: its sign is not a function of y alone
-              const F8 av = load8(act + off);
+              const F8 av = ld(act + off);
 #pragma unroll
               for (int i = 0; i < 8; ++i) dv.v[i] = av.v[i] > 0.f ? dv.v[i] : 0.f;
             } else {    // recompute the ReLU decision from y (saves one activation read)
@@ -133,7 +175,7 @@ __global__ void bn_reduce_kernel(const T* __restrict__ y, const T* dout, const T
               for (int i = 0; i < 8; ++i) dv.v[i] = fmaf(yv.v[i], sc[i], sh[i]) > 0.f ? dv.v[i] : 0.f;
             }
           }
-          if (WRITE_DZ) store8(dz_out + off, dv);
+          if (WRITE_DZ) st(dz_out + off, dv);
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             a1[i] += dv.v[i];
@@ -275,7 +317,7 @@ __device__ __forceinline__ uint8_t positive_bits(const F8& o) {
 }
 
 // out = act(y * scale[g] + shift[g] (+ residual)); bits (nullable): [row][C/8] ReLU decisions of out
-template <typename T>
+template <typename T, int NT = 0>
 __global__ __launch_bounds__(NTHR) void bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ scale,
                                                         const float* __restrict__ shift,
                                                         const T* __restrict__ residual, T* __restrict__ out, int C,
@@ -292,10 +334,10 @@ __global__ __launch_bounds__(NTHR) void bn_apply_kernel(const T* __restrict__ y,
       const size_t off = base + (size_t)r * C;
       F8 yv[4], rv[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) yv[u] = load8(y + off + u * rstride);
+      for (int u = 0; u < 4; ++u) yv[u] = (NT & 1) ? load8_nt(y + off + u * rstride) : load8(y + off + u * rstride);
       if (residual) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) rv[u] = load8(residual + off + u * rstride);
+        for (int u = 0; u < 4; ++u) rv[u] = (NT & 1) ? load8_nt(residual + off + u * rstride) : load8(residual + off + u * rstride);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -310,18 +352,19 @@ __global__ __launch_bounds__(NTHR) void bn_apply_kernel(const T* __restrict__ y,
 #pragma unroll
           for (int i = 0; i < 8; ++i) o.v[i] = fmaxf(o.v[i], 0.f);
         }
-        store8(out + off + u * rstride, o);
+        if (NT & 2) store8_nt(out + off + u * rstride, o);
+        else store8(out + off + u * rstride, o);
         if (bits) bits[(off + u * rstride) >> 3] = positive_bits(o);
       }
     }
     for (; r < w.r_end; r += w.RL) {
       const size_t off = base + (size_t)r * C;
-      const F8 yv = load8(y + off);
+      const F8 yv = (NT & 1) ? load8_nt(y + off) : load8(y + off);
       F8 o;
 #pragma unroll
       for (int i = 0; i < 8; ++i) o.v[i] = fmaf(yv.v[i], sc.v[i], sh.v[i]);
       if (residual) {
-        const F8 rv = load8(residual + off);
+        const F8 rv = (NT & 1) ? load8_nt(residual + off) : load8(residual + off);
 #pragma unroll
         for (int i = 0; i < 8; ++i) o.v[i] += rv.v[i];
       }
@@ -329,14 +372,15 @@ __global__ __launch_bounds__(NTHR) void bn_apply_kernel(const T* __restrict__ y,
 #pragma unroll
         for (int i = 0; i < 8; ++i) o.v[i] = fmaxf(o.v[i], 0.f);
       }
-      store8(out + off, o);
+      if (NT & 2) store8_nt(out + off, o);
+      else store8(out + off, o);
       if (bits) bits[off >> 3] = positive_bits(o);
     }
   }
 }
 
 // dy = scale * (dz - s1/cnt - xhat * s2/cnt) = ka*dz + kb*y + kc per (group, channel); optionally dres = dz
-template <typename T>
+template <typename T, int NT = 0>
 __global__ __launch_bounds__(NTHR) void bn_bwd_apply_kernel(
     const T* __restrict__ y, const T* __restrict__ dout, const T* __restrict__ act, const float* __restrict__ mean,
     const float* __restrict__ invstd, const float* __restrict__ scale, const float* __restrict__ shift,
@@ -372,11 +416,15 @@ __global__ __launch_bounds__(NTHR) void bn_bwd_apply_kernel(
           for (int i = 0; i < 8; ++i) dv.v[i] = av.v[i] > 0.f ? dv.v[i] : 0.f;
         }
       }
-      if (dres) store8(dres + off, dv);
+      if (dres) {
+        if (NT & 2) store8_nt(dres + off, dv);
+        else store8(dres + off, dv);
+      }
       F8 o;
 #pragma unroll
       for (int i = 0; i < 8; ++i) o.v[i] = fmaf(sc.v[i], dv.v[i], fmaf(kb.v[i], yv.v[i], kc.v[i]));
-      store8(dy + off, o);
+      if (NT & 2) store8_nt(dy + off, o);
+      else store8(dy + off, o);
     };
     int r = w.r_begin + w.rl;
     for (; r + 3 * w.RL < w.r_end; r += 4 * w.RL) {
@@ -384,12 +432,12 @@ __global__ __launch_bounds__(NTHR) void bn_bwd_apply_kernel(
       F8 yv[4], dv[4], av[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        yv[u] = load8(y + off + u * rstride);
-        dv[u] = load8(dout + off + u * rstride);
+        yv[u] = (NT & 1) ? load8_nt(y + off + u * rstride) : load8(y + off + u * rstride);
+        dv[u] = (NT & 1) ? load8_nt(dout + off + u * rstride) : load8(dout + off + u * rstride);
       }
       if (relu && !recompute) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) av[u] = load8(act + off + u * rstride);
+        for (int u = 0; u < 4; ++u) av[u] = (NT & 1) ? load8_nt(act + off + u * rstride) : load8(act + off + u * rstride);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) one(off + u * rstride, yv[u], dv[u], av[u]);
@@ -794,15 +842,23 @@ int launch_reduce(const void* y, const void* dout, const void* act, const float*
     const size_t n = (size_t)G * C;
     float* ws = vc_det_workspace(2 * n * grid.x, stream, "BatchNorm reduction");
     if (!ws) return VC_ERR_ARG;
-    hipLaunchKernelGGL((bn_reduce_kernel<T, MODE, WRITE_DZ>), grid, dim3(NTHR), 0, stream, (const T*)y, (const T*)dout,
-                       (const T*)act, mean, invstd, scale, shift, ws, ws + n * grid.x, C, rpg, rows_per_block, relu,
-                       (T*)dz_out, bits, n);
+    hipLaunchKernelGGL((bn_reduce_kernel<T, MODE, WRITE_DZ, 0>), grid, dim3(NTHR), 0, stream, (const T*)y,
+                       (const T*)dout, (const T*)act, mean, invstd, scale, shift, ws, ws + n * grid.x, C, rpg,
+                       rows_per_block, relu, (T*)dz_out, bits, n);
     vc_det_reduce(s1, ws, n, (int)grid.x, stream);
     return vc_det_reduce(s2, ws + n * grid.x, n, (int)grid.x, stream);
   }
-  hipLaunchKernelGGL((bn_reduce_kernel<T, MODE, WRITE_DZ>), grid, dim3(NTHR), 0, stream, (const T*)y, (const T*)dout,
-                     (const T*)act, mean, invstd, scale, shift, s1, s2, C, rpg, rows_per_block, relu, (T*)dz_out,
-                     bits, (size_t)0);
+#define VC_BN_REDUCE(NT_)                                                                                     \
+  hipLaunchKernelGGL((bn_reduce_kernel<T, MODE, WRITE_DZ, NT_>), grid, dim3(NTHR), 0, stream, (const T*)y,    \
+                     (const T*)dout, (const T*)act, mean, invstd, scale, shift, s1, s2, C, rpg, rows_per_block, \
+                     relu, (T*)dz_out, bits, (size_t)0)
+  switch (MODE == 1 && sizeof(T) == 2 ? (bn_nt_policy((size_t)G * rpg * C * 2) >> 4) & 3 : 0) {
+    case 1: VC_BN_REDUCE(1); break;
+    case 2: VC_BN_REDUCE(2); break;
+    case 3: VC_BN_REDUCE(3); break;
+    default: VC_BN_REDUCE(0); break;
+  }
+#undef VC_BN_REDUCE
   return VC_OK;
 }
 
@@ -928,10 +984,18 @@ int vc_bn_apply_mask(int dtype, const void* y, const float* scale, const float* 
   VC_CHECK_SHAPE(G > 0 && G < 65536 && rpg > 0, "vc_bn_apply: bad group count %d", G);
   const int rows = apply_rows_per_block(G, rpg, C);
   const dim3 grid(ceil_div(rpg, rows), G);
-  if (dtype == VC_BF16)
-    hipLaunchKernelGGL((bn_apply_kernel<bf16>), grid, dim3(NTHR), 0, stream, (const bf16*)y, scale, shift,
-                       (const bf16*)residual, (bf16*)out, C, rpg, rows, relu, bits);
-  else if (dtype == VC_F32)
+  if (dtype == VC_BF16) {
+    switch (bn_nt_policy((size_t)G * rpg * C * 2) & 3) {
+#define VC_BN_APPLY(NT_)                                                                                     \
+  hipLaunchKernelGGL((bn_apply_kernel<bf16, NT_>), grid, dim3(NTHR), 0, stream, (const bf16*)y, scale, shift, \
+                     (const bf16*)residual, (bf16*)out, C, rpg, rows, relu, bits)
+      case 1: VC_BN_APPLY(1); break;
+      case 2: VC_BN_APPLY(2); break;
+      case 3: VC_BN_APPLY(3); break;
+      default: VC_BN_APPLY(0); break;
+#undef VC_BN_APPLY
+    }
+  } else if (dtype == VC_F32)
     hipLaunchKernelGGL((bn_apply_kernel<float>), grid, dim3(NTHR), 0, stream, (const float*)y, scale, shift,
                        (const float*)residual, (float*)out, C, rpg, rows, relu, bits);
   else { vc_set_error("vc_bn_apply: unsupported dtype %d", dtype); return VC_ERR_DTYPE; }
@@ -989,11 +1053,19 @@ int vc_bn_bwd_apply(int dtype, const void* y, const void* dout, const void* act,
   const float inv_cnt = 1.f / (float)rpg;
   const int rows = apply_rows_per_block(G, rpg, C);
   const dim3 grid(ceil_div(rpg, rows), G);
-  if (dtype == VC_BF16)
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16>), grid, dim3(NTHR), 0, stream, (const bf16*)y, (const bf16*)dout,
-                       (const bf16*)act, mean, invstd, scale, shift, s1, s2, (bf16*)dy, (bf16*)dres, C, rpg, rows,
-                       inv_cnt, relu);
-  else if (dtype == VC_F32)
+  if (dtype == VC_BF16) {
+    switch ((bn_nt_policy((size_t)G * rpg * C * 2) >> 2) & 3) {
+#define VC_BN_BWD_APPLY(NT_)                                                                                          \
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, NT_>), grid, dim3(NTHR), 0, stream, (const bf16*)y, (const bf16*)dout, \
+                     (const bf16*)act, mean, invstd, scale, shift, s1, s2, (bf16*)dy, (bf16*)dres, C, rpg, rows,     \
+                     inv_cnt, relu)
+      case 1: VC_BN_BWD_APPLY(1); break;
+      case 2: VC_BN_BWD_APPLY(2); break;
+      case 3: VC_BN_BWD_APPLY(3); break;
+      default: VC_BN_BWD_APPLY(0); break;
+#undef VC_BN_BWD_APPLY
+    }
+  } else if (dtype == VC_F32)
     hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), grid, dim3(NTHR), 0, stream, (const float*)y, (const float*)dout,
                        (const float*)act, mean, invstd, scale, shift, s1, s2, (float*)dy, (float*)dres, C, rpg, rows,
                        inv_cnt, relu);
