@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--only", default=None, help="run only the layers with these names, comma separated (for counter collection)")
     ap.add_argument("--passes", default="fwd,dgrad,wgrad")
+    ap.add_argument("--stats", action="store_true",
+                    help="forward pass with the BatchNorm slab sums in its epilogue (vc_conv_fwd_stats), as in a training step")
     ap.add_argument("--flush", action="store_true",
                     help="overwrite a 1 GiB buffer before every timed launch: operands come from HBM as inside a "
                          "training step, not from the 256 MB infinity cache the previous repetition left warm")
@@ -100,7 +102,12 @@ def main():
 
         t_f = t_d = t_w = float("nan")
         if "fwd" in passes:
-            t_f = run(lambda: L.call("vc_conv_fwd", desc, 1, L.ptr(x), 0, L.ptr(wf), L.ptr(None), L.ptr(y), 0, 0, 0, 0, st))
+            if args.stats and L.lib().vc_conv_fwd_stats_supported(desc, 1, 0, 0):
+                part = torch.empty(N * Ho * Wo // 64, 2, Co, device=dev, dtype=torch.float32)
+                t_f = run(lambda: L.call("vc_conv_fwd_stats", desc, 1, L.ptr(x), 0, L.ptr(wf), L.ptr(None), L.ptr(y), 0, 0,
+                                         L.ptr(part), st))
+            else:
+                t_f = run(lambda: L.call("vc_conv_fwd", desc, 1, L.ptr(x), 0, L.ptr(wf), L.ptr(None), L.ptr(y), 0, 0, 0, 0, st))
         if Ci % 8 == 0 and "dgrad" in passes:
             t_d = run(lambda: L.call("vc_conv_dgrad", desc, 1, L.ptr(dy), 0, L.ptr(wt), L.ptr(dx), 0, 0, 0, st))
         if "wgrad" in passes:

@@ -524,17 +524,12 @@ constexpr int EPI_NONE = 0, EPI_BN_TAIL = 1, EPI_RESIDUAL = 2, EPI_GELU_BWD = 3,
 __device__ __forceinline__ float gelu_dev(float x) { return vc_gelu(x); }
 __device__ __forceinline__ float gelu_grad_dev(float x) { return vc_gelu_grad(x); }
 
-// 16-byte accesses of the output tile and of an epilogue's side tensor
-#ifndef VC_EPI_NT
-#define VC_EPI_NT 0
-#endif
+// 16-byte store of an output-tile row: non-temporal, the tile is not read again by this kernel and the consumers
+// stream it from memory anyway (measured per step, stores only: ResNet-50 CRNN 46.30 -> 46.13 ms, Swin-RNN with 32
+// clips 53.64 -> 52.75 ms, with 8 clips 17.93 -> 17.85 ms; non-temporal loads of the epilogues' side tensors on top:
+// +0.1 ms on the ResNet step)
 __device__ __forceinline__ void epi_store8(bf16* p, const bf16x8& v) {
-  if (VC_EPI_NT & 1) __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(p));
-  else *reinterpret_cast<bf16x8*>(p) = v;
-}
-__device__ __forceinline__ bf16x8 epi_load8(const bf16* p) {
-  if (VC_EPI_NT & 2) return __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p));
-  return *reinterpret_cast<const bf16x8*>(p);
+  __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(p));
 }
 
 template <int MODE, int WI, int EPI = EPI_NONE, bool HAS_BIAS = true>
@@ -575,7 +570,12 @@ __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[
   constexpr int RPI = 64 / NCH;  // image rows per store instruction (8 or 16)
   const int rr = lane / NCH, ch = lane % NCH;
   const int co = n0 + wn * WC + ch * 8;
-  float ps[8], pq[8];  // per-channel sum / sum of squares of the values as stored (BatchNorm statistics)
+  // per-channel sum / sum of squares of the values as stored (BatchNorm statistics).  They cost the write-heavy
+  // forward layers up to a third of their time (64 -> 256 channels at 56 x 56: 0.246 -> 0.327 ms, about 0.85 ms per
+  // ResNet-50 step over all layers) and are still cheaper than a pass over y.  Two cheaper-looking forms measured
+  // SLOWER: channel pairs on packed fp32 instructions (that layer 0.379 ms, step +1.1 ms), and a fold in which the
+  // lanes exchange halves (14 exchanges instead of 48; 48 bytes of scratch at the 256-register limit, step +3.6 ms).
+  float ps[8], pq[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) ps[e] = pq[e] = 0.f;
   constexpr int NIT = 64 / RPI;
@@ -605,10 +605,10 @@ __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[
     const bool live = m < g.M && co < g.Co;
     orow[it] = live ? out + (size_t)(MODE == 2 ? phase_out_pixel(g, m) : m) * g.ldc + co : nullptr;
     oldv[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    if (beta && live && vec) oldv[it] = epi_load8(orow[it]);
+    if (beta && live && vec) oldv[it] = *reinterpret_cast<const bf16x8*>(orow[it]);
     if (SIDE_IN) {
       tyv[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-      if (live) tyv[it] = epi_load8(tail_y + (size_t)m * g.Co + co);
+      if (live) tyv[it] = *reinterpret_cast<const bf16x8*>(tail_y + (size_t)m * g.Co + co);
     }
     if (TAIL) {
       tbits[it] = 0;

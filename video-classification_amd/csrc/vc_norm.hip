@@ -648,19 +648,6 @@ __global__ void bn_bwd_params_kernel(float* __restrict__ s1, float* __restrict__
 // ------------------------------ LayerNorm ---------------------------------
 // A row is handled by LPR lanes (16, 32 or 64 = one wave), so that narrow rows (Swin stage 1: C = 96 = 12
 // 16-byte chunks) still keep most lanes busy: a wave normalises 64/LPR rows at once.  C % 8 == 0.
-#ifndef VC_LN_NT
-#define VC_LN_NT 0
-#endif
-template <int BIT, typename T>
-__device__ __forceinline__ F8 ln_load8(const T* p) {
-  return (VC_LN_NT & BIT) ? load8_nt(p) : load8(p);
-}
-template <int BIT, typename T>
-__device__ __forceinline__ void ln_store8(T* p, const F8& v) {
-  if (VC_LN_NT & BIT) store8_nt(p, v);
-  else store8(p, v);
-}
-
 template <int LPR>
 __device__ __forceinline__ float group_sum(float v) {
 #pragma unroll
@@ -704,11 +691,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     rstd[row] = rs;
   }
   for (int cc = sub; cc < C8; cc += LPR) {
-    const F8 v = ln_load8<4>(xr + cc * 8), ga = load8(gamma + cc * 8), be = load8(beta + cc * 8);
+    const F8 v = load8(xr + cc * 8), ga = load8(gamma + cc * 8), be = load8(beta + cc * 8);
     F8 o;
 #pragma unroll
     for (int i = 0; i < 8; ++i) o.v[i] = fmaf((v.v[i] - mu) * rs, ga.v[i], be.v[i]);
-    ln_store8<8>(out + (size_t)row * C + cc * 8, o);
+    store8(out + (size_t)row * C + cc * 8, o);
   }
 }
 
@@ -752,8 +739,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
     for (int k = 0; k < NCH; ++k) {
       const int cc = sub + LPR * k;
       if (cc < C8) {
-        xv[k] = ln_load8<1>(x + ro + cc * 8);
-        dv[k] = ln_load8<1>(dout + ro + cc * 8);
+        xv[k] = load8(x + ro + cc * 8);
+        dv[k] = load8(dout + ro + cc * 8);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const float xh = (xv[k].v[i] - mu) * rs, dg = dv[k].v[i] * ga[k].v[i];
@@ -778,11 +765,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
 #pragma unroll
           for (int i = 0; i < 8; ++i) o.v[i] = rs * (dv[k].v[i] * ga[k].v[i] - a - xv[k].v[i] * b);
           if (add) {  // gradient that reaches x past the normalisation (the residual stream)
-            const F8 r = ln_load8<1>(add + ro + cc * 8);
+            const F8 r = load8(add + ro + cc * 8);
 #pragma unroll
             for (int i = 0; i < 8; ++i) o.v[i] += r.v[i];
           }
-          ln_store8<2>(dx + ro + cc * 8, o);
+          store8(dx + ro + cc * 8, o);
         }
       }
     }
