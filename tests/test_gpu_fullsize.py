@@ -195,9 +195,14 @@ def test_resnet152_crnn_ucf_shape(cuda, dt):
     torch.cuda.synchronize()
     ops.check_lstm_error()
     f32 = dt == torch.float32
+    # fp32, fc1 / bn1: one of the 96 x 1024 inputs of the head's first ReLU lies within the trunk's run-to-run noise
+    # (1e-6, the order of fp32 atomics) of zero on this seed, so its ReLU decision -- and with it the gradient of that
+    # channel -- lands on either side from run to run: 1.5e-5 when it agrees with the oracle's, 3.3e-3 when it does not
+    # (measured 4 : 6 over ten runs, the same two values every time).  Everything behind that ReLU stays below 2e-5.
     _compare(mine, out, loss.item(), ref_out, ref_loss, ref_grads, dt, 2e-2 if f32 else 0.9,
              cancelled=["encoder.fc1.bias", "encoder.fc2.bias"],
-             group_tol={"decoder.": 1e-4, "encoder.fc": 1e-4, "encoder.bn": 1e-4} if f32 else
+             group_tol={"decoder.": 1e-4, "encoder.fc2": 1e-4, "encoder.fc3": 1e-4, "encoder.bn2": 1e-4,
+                        "encoder.fc1": 1e-2, "encoder.bn1": 1e-2} if f32 else
              {"decoder.fc2": 3e-2, "decoder.": 0.12})
     if not f32:
         e = _resnet_ref(True, "resnet152", 3, 6)
