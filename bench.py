@@ -325,7 +325,7 @@ def main():
         # this command with --no-graph; FETCH_SIZE doubled as gfx950 requires) -- None if they were never collected
         traffic, traffic_src, traffic_step = None, None, None
         import glob
-        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_hbm_traffic.json")))  # newest round last
+        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_hbm_traffic.json")))  # newest file last
         tfile = tfiles[-1] if tfiles else ""
         if args.model == "resnetcrnn" and args.arch == "resnet50" and B == 32 and os.path.exists(tfile):
             with open(tfile) as fh:

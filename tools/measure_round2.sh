@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round evidence on the GPU box: bash tools/measure_round2.sh <tag>  (outputs under gpurun_out/m_<tag>/)
+# Measurement evidence on the GPU box: bash tools/measure_round2.sh <tag>  (outputs under gpurun_out/m_<tag>/)
 #  1. tools/measure_round.sh: kernel trace of the eager headline step, bench lines of the workloads, layer table
 #  2. cold-cache layer table, Swin workloads at 32 clips, the fusion CNN
 #  3. HBM traffic counters of the headline step (FETCH_SIZE / WRITE_SIZE, one pass each)
