@@ -324,6 +324,7 @@ __global__ void colsum_vec_kernel(const T* __restrict__ a, float* __restrict__ o
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = 0.f;
     if (rl < RL && cvalid) {
+#pragma unroll 4
       for (int r = r_begin + rl; r < r_end; r += RL) {
         const F8 v = load8(a + (size_t)r * C + cc * 8);
 #pragma unroll
@@ -624,7 +625,9 @@ int vc_cast(int src_dtype, int dst_dtype, const void* a, void* out, int64_t n, h
 int vc_colsum(int dtype, const void* a, float* out, int M, int C, int lda, hipStream_t stream) {
   VC_CHECK_ARG(a && out && M > 0 && C > 0 && lda >= C, "vc_colsum: bad argument");
   const bool vec = lda % 8 == 0;
-  int rows_per_block = vec ? 256 : 64;
+  // a block's threads walk their rows one load after the other, so short matrices (the LSTM's 512 x 2048 gate
+  // gradients) are cut into many blocks of few rows: 256 rows per block took 53 us there
+  int rows_per_block = vec ? 16 : 64;
   while (ceil_div(M, rows_per_block) > (vec ? 1024 : 512)) rows_per_block *= 2;
   const int slots = ceil_div(M, rows_per_block);
   // deterministic mode: a copy of out per block of rows, added in block order afterwards
