@@ -228,7 +228,8 @@ __global__ void bn_partial_reduce_kernel(const float* __restrict__ partial, floa
   if (c >= C) return;
   const int s0 = blockIdx.y * chunk, s1 = min(spg, s0 + chunk);
   float a = 0.f, b = 0.f;
-  for (int sl = s0; sl < s1; ++sl) {
+#pragma unroll 8
+  for (int sl = s0; sl < s1; ++sl) {  // unrolled: the loads of eight slabs in flight, the sums in slab order
     const float* p = partial + ((size_t)g * spg + sl) * 2 * C;
     a += p[c];
     b += p[C + c];
