@@ -45,7 +45,9 @@ const char* vc_last_error(void);
  * loss) are added in a fixed order, so that a training step repeats bit for bit.  workspace: device memory of the
  * CURRENT device (at least 2^20 floats; 2^26 cover the ResNet-50 CRNN step at 32 clips without cutting a weight
  * gradient into fewer splits), owned by the caller, kept alive while the mode is on; call once per device, and issue
- * the library's calls on one stream at a time per device.  on == 0 switches the mode off on every device.  Covered
+ * the library's calls on one stream at a time per device.  on == 0 switches the mode off on every device.  The mode's
+ * state is safe to switch from another host thread, but a workspace must outlive every call already issued with it:
+ * do not switch the mode off (and free the workspace) while another thread is inside a library call.  Covered
  * besides the above: LayerNorm gamma / beta gradients and the relative-position-bias gradient of window attention
  * (bf16 path).  Not covered: the CBAM gradients of the fusion CNN and the fp32 attention kernel. */
 int vc_set_deterministic(int on, float* workspace, size_t workspace_floats);

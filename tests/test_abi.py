@@ -74,7 +74,8 @@ def test_only_known_kernels_spill():
     """Kernel resource use is read from the code objects inside the built library (no GPU needed).  A kernel that
     starts spilling at the 256-register limit loses a large factor silently (measured: 20-96 bytes of scratch in two
     GEMM epilogue variants cost the Swin step 3 %), so the set of kernels that use scratch memory is pinned: the
-    window-attention backward, which holds its bias tables and both accumulator sets in all 512 registers."""
+    window-attention backward, which holds its bias tables and both accumulator sets in all 512 registers, and the
+    experimental 8-wave NT kernel (off unless VC_NT8=1), whose epilogue parks loop-invariant addresses in scratch."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import check_spills
@@ -82,4 +83,4 @@ def test_only_known_kernels_spill():
     ks = check_spills.kernels(L.LIB_PATH)
     assert len(ks) > 150
     spilling = sorted(k[".name"] for k in ks if k.get(".private_segment_fixed_size", 0) > 0)
-    assert all("window_attn_bwd_mfma_kernel" in n for n in spilling), spilling
+    assert all("window_attn_bwd_mfma_kernel" in n or "igemm_nt8_kernel" in n for n in spilling), spilling

@@ -275,6 +275,28 @@ def test_fused_optimizer_resumes_torch_state(cuda, name):
         assert p.grad.data_ptr() == opt_m.flat.view_of(opt_m.flat.grad, i).data_ptr()
 
 
+def test_fused_optimizer_parameter_without_gradient_after_set_to_none(cuda):
+    """A parameter that received a gradient in step 1 and none in step 2, with the caller clearing gradients by
+    model.zero_grad(set_to_none=True) (which does not touch the flat buffer): step 2 must see a zero gradient for it,
+    not step 1's.  SGD without momentum or weight decay: such a parameter must not move in step 2."""
+    from video_classification_amd import trainer as TR
+    torch.manual_seed(3)
+    net = nn.Sequential(nn.Linear(6, 4), nn.Linear(4, 2)).to(cuda)
+    opt = TR.FusedOptimizer(net, "sgd", lr=0.1, momentum=0.0, weight_decay=0.0)
+    for p in net.parameters():
+        p.grad = torch.ones_like(p)
+    opt.step()
+    before = [p.detach().clone() for p in net.parameters()]
+    net.zero_grad(set_to_none=True)
+    for p in net[0].parameters():  # only the first layer gets a gradient this time
+        p.grad = torch.ones_like(p)
+    opt.step()
+    after = [p.detach() for p in net.parameters()]
+    for i, (b, a) in enumerate(zip(before, after)):
+        moved = (a - b).abs().max().item()
+        assert (abs(moved - 0.1) < 1e-6) if i < 2 else (moved == 0.0), (i, moved)
+
+
 @pytest.mark.parametrize("dt", DTYPES, ids=IDS)
 def test_dropout_statistics_and_backward(cuda, dt):
     from video_classification_amd import ops

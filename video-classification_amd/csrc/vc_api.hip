@@ -1,15 +1,23 @@
 // Library-level entry points of libvc_hip: version, last-error string.
 #include <stdarg.h>
 
+#include <atomic>
+#include <mutex>
+
 #include "vc_common.h"
 
 namespace {
 thread_local char g_err[512] = "";
 
-constexpr int MAX_DEV = 64;
-int g_det = 0;
+constexpr int MAX_DEV = VC_MAX_DEVICES;
+// Deterministic-mode state: the flag is atomic and the per-device tables are read and written under g_det_mu, so a
+// host thread that switches the mode never hands another thread a half-updated (workspace, size) pair.  A launcher that
+// has already fetched its workspace keeps using it: the caller must not free a workspace while calls are in flight.
+std::atomic<int> g_det{0};
+std::mutex g_det_mu;
 float* g_det_ws[MAX_DEV] = {};
 size_t g_det_floats[MAX_DEV] = {};
+std::atomic<int> g_cus[MAX_DEV];  // compute units per device, 0 = not asked yet
 
 int current_device() {
   int dev = 0;
@@ -56,21 +64,30 @@ bool vc_deterministic() { return g_det != 0; }
 
 size_t vc_det_capacity() {
   const int dev = current_device();
-  return dev < 0 ? 0 : g_det_floats[dev];
+  if (dev < 0) return 0;
+  std::lock_guard<std::mutex> lock(g_det_mu);
+  return g_det_floats[dev];
 }
 
 float* vc_det_workspace(size_t floats, hipStream_t stream, const char* who) {
   const int dev = current_device();
-  if (dev < 0 || !g_det_ws[dev] || g_det_floats[dev] < floats) {
+  float* ws = nullptr;
+  size_t have = 0;
+  if (dev >= 0) {  // one consistent (pointer, size) pair
+    std::lock_guard<std::mutex> lock(g_det_mu);
+    ws = g_det_ws[dev];
+    have = g_det_floats[dev];
+  }
+  if (!ws || have < floats) {
     vc_set_error("%s: deterministic mode needs a workspace of %zu floats on this device, vc_set_deterministic registered %zu",
-                 who, floats, dev < 0 ? (size_t)0 : g_det_floats[dev]);
+                 who, floats, have);
     return nullptr;
   }
-  if (hipMemsetAsync(g_det_ws[dev], 0, floats * sizeof(float), stream) != hipSuccess) {
+  if (hipMemsetAsync(ws, 0, floats * sizeof(float), stream) != hipSuccess) {
     vc_set_error("%s: clearing the deterministic-mode workspace failed: %s", who, hipGetErrorString(hipGetLastError()));
     return nullptr;
   }
-  return g_det_ws[dev];
+  return ws;
 }
 
 int vc_det_reduce(float* out, const float* ws, size_t n, int slots, hipStream_t stream) {
@@ -90,11 +107,17 @@ void vc_set_error(const char* fmt, ...) {
 // 256 (MI355X) when no device can be asked, e.g. on a build host.
 int vc_device_cus() {
   int dev = 0, n = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-      n <= 0) {
+  if (hipGetDevice(&dev) != hipSuccess) {
     (void)hipGetLastError();
     return 256;
   }
+  const bool cached = dev >= 0 && dev < MAX_DEV;
+  if (cached && (n = g_cus[dev].load(std::memory_order_relaxed)) > 0) return n;  // one attribute query per device
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    return 256;
+  }
+  if (cached) g_cus[dev].store(n, std::memory_order_relaxed);
   return n;
 }
 
@@ -110,6 +133,7 @@ const char* vc_last_error(void) { return g_err; }
 // the mode is on) holds the per-block partial sums; call once per device.  Calls that use it must be issued on one
 // stream at a time per device.  on == 0 switches the mode off for every device and forgets the workspaces.
 int vc_set_deterministic(int on, float* workspace, size_t workspace_floats) {
+  std::lock_guard<std::mutex> lock(g_det_mu);
   if (!on) {
     g_det = 0;
     for (int d = 0; d < MAX_DEV; ++d) {

@@ -30,6 +30,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 #define VC_ERR_ARG (-4)
 
 void vc_set_error(const char* fmt, ...);
+constexpr int VC_MAX_DEVICES = 64;  // per-device tables of the library (workspaces, scratch addresses, CU counts)
 int vc_device_cus();  // compute units of the current device (256 if no device answers)
 // Deterministic mode (vc_set_deterministic): sums that blocks otherwise combine with fp32 atomics, in whatever order
 // they finish, go through a workspace instead -- block (slot) s adds into ws[s * n + i], and vc_det_reduce then does

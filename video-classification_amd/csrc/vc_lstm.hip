@@ -372,7 +372,7 @@ __global__ __launch_bounds__(LTHR, 1) void lstm_persist_bwd_kernel(LstmBwdArgs a
 constexpr size_t SCRATCH_BYTES = 512u << 10;  // e.g. both directions of B <= 64, H = 512 or of B <= 32, H = 1024
 static __device__ __align__(256) __attribute__((used)) unsigned char scratch[SCRATCH_BYTES];
 
-constexpr int MAX_DEVICES = 64;
+constexpr int MAX_DEVICES = VC_MAX_DEVICES;
 void* g_scratch_ptr[MAX_DEVICES];  // zero-initialised; written once per device
 std::mutex g_scratch_mutex;
 

@@ -656,7 +656,10 @@ __global__ __launch_bounds__(64 * AW, 1) __attribute__((amdgpu_waves_per_eu(1, 1
     // the stores' acknowledgements (several microseconds under load); they get the whole window to arrive, because
     // the next wait that covers them is the next window's.  Register spills only add instructions behind the
     // requests, which makes the bound conservative.
-    if (stored) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    // The count of 24 holds when every 16-row tile of the window has a live row (N > 48, i.e. 7 x 7 windows): with
+    // fewer tokens the stores of an empty tile may be branched over, fewer than 24 are issued and the bound would
+    // release before the tiles have landed.  Smaller windows wait for everything.
+    if (stored && N > 48) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wave_lds_fence();
     // the next window's tiles go into the other set, whose last reader was the window before this one (the LDS serves

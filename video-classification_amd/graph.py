@@ -52,6 +52,10 @@ class GraphedTrainStep:
                 self.opt.flat.zero_grad()
                 out = model(self.x)
                 self.loss = criterion(out, self.y)
+                # the tensors the captured loss kernel writes: an eager call of the same criterion (validation, a
+                # short last batch) rebinds criterion.stats to fresh tensors, so replays must hand out THESE
+                stats = getattr(criterion, "stats", None) or {}
+                self.correct, self.pred = stats.get("correct"), stats.get("pred")
                 cuts, ops._cut_recorder = (ops._cut_recorder or []), None
                 if cuts:
                     grad = torch.autograd.grad([self.loss], [cuts[-1]])[0]
@@ -121,6 +125,8 @@ class GraphedTrainStep:
                 b.finish()
             self.opt.launch()
         self.opt.after_step()
+        if self.correct is not None:  # the criterion reports what this replay computed
+            self.crit.stats["correct"], self.crit.stats["pred"] = self.correct, self.pred
         return self.loss
 
 

@@ -115,6 +115,27 @@ class SwinT(nn.Module):
                 if m.bias is not None:
                     nn.init.zeros_(m.bias)
 
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        """Accepts both timm checkpoint layouts of swin_tiny_patch4_window7_224 (the reference builds its backbone with
+        an unpinned timm, model_components.py:254, 412): timm >= 0.9 puts a stage's PatchMerging at the START of
+        layers.{1,2,3} and keeps no index / mask buffers; older timm puts it at the END of layers.{0,1,2} and stores
+        persistent ``attn.relative_position_index`` and ``attn_mask`` buffers.  The buffers are derived from the
+        geometry by the kernels, a classifier ``head`` does not exist at num_classes=0: those keys are dropped, the
+        older downsample keys are renamed.  Runs before the children load, on the dict load_state_dict passes down."""
+        mine = [k for k in state_dict if k.startswith(prefix)]
+        for k in mine:
+            rest = k[len(prefix):]
+            if rest.endswith("attn.relative_position_index") or rest.endswith(".attn_mask") or rest.startswith("head."):
+                del state_dict[k]
+        if any(k.startswith(prefix + "layers.0.downsample.") for k in state_dict):  # the older layout
+            for i in range(len(self.layers) - 2, -1, -1):
+                src = f"{prefix}layers.{i}.downsample."
+                for k in [k for k in state_dict if k.startswith(src)]:
+                    state_dict[f"{prefix}layers.{i + 1}.downsample.{k[len(src):]}"] = state_dict.pop(k)
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                                      error_msgs)
+
     def run(self, a):
         """a: channels-last frames [F,1,H,W,8] -> [F, num_features]."""
         pe = self.patch_embed

@@ -111,6 +111,7 @@ class FusedOptimizer(torch.optim.Optimizer):
             view = flat.view_of(flat.grad, i)
             g = p.grad
             if g is None:
+                view.zero_()  # no gradient this step: the slice still holds the previous step's
                 p.grad = view
             elif g.data_ptr() != view.data_ptr():
                 view.copy_(g)
@@ -396,8 +397,12 @@ def _graphed_batch(model, criterion, optimizer, data, target):
     short last batch of an epoch) run eagerly."""
     from .graph import GraphedTrainStep
     tgt = target.reshape(-1)
-    key = (tuple(data.shape), data.dtype, tuple(tgt.shape))
+    # the graph is bound to the flat buffers of ONE optimizer and to ONE criterion's statistics: a call with another
+    # of either builds a new graph instead of replaying into the old buffers
+    key = (tuple(data.shape), data.dtype, tuple(tgt.shape), id(optimizer), id(criterion))
     cached = getattr(model, "_vc_train_graph", None)
+    if cached is not None and cached[0][3:] != key[3:]:
+        cached = None
     if cached is None:
         gs = GraphedTrainStep(model, optimizer, criterion, data, tgt, warmup=1)
         object.__setattr__(model, "_vc_train_graph", (key, gs))
@@ -405,7 +410,7 @@ def _graphed_batch(model, criterion, optimizer, data, target):
     if cached[0] != key:
         return None
     loss = cached[1](data, tgt)
-    return loss, criterion.stats["correct"]
+    return loss, cached[1].correct
 
 
 def train_epoch(model, train_loader, criterion, optimizer, device, epoch, use_amp=False, scaler=None, logger=None,
