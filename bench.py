@@ -200,7 +200,7 @@ def main():
     model = model.to(dev).set_compute_dtype(dt)
     opt = TR.get_optimizer(model, "adam", lr=1e-4, weight_decay=1e-4)
     trace("model and optimizer built")
-    TR.make_data_parallel(model, opt, bucket_mb=args.bucket_mb)
+    bucketer = TR.make_data_parallel(model, opt, bucket_mb=args.bucket_mb)
     trace("parameters broadcast")
     crit = TR.FusedCrossEntropyLoss()
     ops.manual_seed(1234 + rank)
@@ -295,10 +295,18 @@ def main():
         torch.cuda.synchronize()
         prof, ops.PROFILE = ops.PROFILE, None
         prof_where = f"HIP events around every launch in {prof_steps} eager steps run right after the timed region"
+    # what every rank exchanged: [rank, world as the communicator sees it, all-reduces issued, buckets that had to be
+    # launched by the optimizer's wait instead of from inside the backward pass (not overlapped)]
+    mine = [rank, dist.get_world_size() if dist.is_initialized() else 1, bucketer.launches,
+            getattr(bucketer, "total_late", 0)]
+    exchange = [mine]
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+        rows = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(rows, torch.tensor(mine, dtype=torch.int64, device=dev))
+        exchange = [r.tolist() for r in rows]
 
     dump = os.environ.get("VC_BENCH_DUMP_LAUNCHES")
     if dump and rank == 0:  # one line per contraction launch of the profiled steps, in launch order
@@ -373,6 +381,12 @@ def main():
             "config": {"workload": workload + ", fwd+CE+bwd+all-reduce+Adam",
                        "global_batch": world * B, "frames_per_clip": 16, "parallelism": f"dp{world}",
                        "launch": mode},
+            "exchange": {"backend": dist.get_backend() if dist.is_initialized() else None,
+                         "buckets": len(bucketer.buckets), "bucket_mb": args.bucket_mb,
+                         "per_rank": [{"rank": r, "comm_world": w, "allreduces_issued": n, "late_buckets": late}
+                                      for r, w, n, late in exchange],
+                         "note": "late_buckets = gradient buckets whose all-reduce was not started from inside the "
+                                 "backward pass (0 = every exchange overlapped)"},
             "loss": float(loss.detach()),
             "roofline": roof,
             "whole_step": whole_step,

@@ -5,6 +5,11 @@
     gradient-ready notifications from the kernels' autograd functions, bucket launches, the wait in the optimizer,
     the 1/world factor -- runs on a one-GPU box.
 
+    With WORLD_SIZE=1 VC_DP_FORCE=1 VC_DIST_BACKEND=nccl the same flow runs on a one-rank RCCL communicator (broadcast,
+    side-stream all-reduces with async handles, stream fences, the phased-graph interleave on the real backend);
+    VC_WORKER_PLAIN=1 runs the plain single-rank step instead (no process group, no bucketer) and VC_WORKER_DET=1
+    switches the ordered sums on, so that the two can be compared bit for bit.
+
     python tests/dp_worker.py <mode: eager|graph> <steps> <out file prefix>
 """
 import os
@@ -37,8 +42,12 @@ def main():
     mode, steps, prefix = sys.argv[1], int(sys.argv[2]), sys.argv[3]
     from video_classification_amd import ops
     from video_classification_amd import trainer as TR
-    rank, local_rank, world = TR.init_distributed()
+    plain = os.environ.get("VC_WORKER_PLAIN", "0") == "1"
+    rank, local_rank, world = (0, 0, 1) if plain else TR.init_distributed()
     dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if os.environ.get("VC_WORKER_DET", "0") == "1":
+        ops.set_deterministic(True, workspace_mb=64)
     model = build(dev)
     if rank != 0:  # rank 0's weights must win: start the others from something else
         with torch.no_grad():
@@ -46,10 +55,15 @@ def main():
                 p.add_(0.5)
     opt = TR.get_optimizer(model, "sgd", lr=1e-2, weight_decay=1e-4)  # linear in the gradient (see the test)
     # small buckets: several per phase of the backward pass
-    bucketer = TR.make_data_parallel(model, opt, bucket_mb=1)
+    import torch.distributed as dist
+    if plain:
+        bucketer = types.SimpleNamespace(buckets=[], late=0, launches=0)
+    else:
+        bucketer = TR.make_data_parallel(model, opt, bucket_mb=1)
     crit = TR.FusedCrossEntropyLoss()
     model.train()
-    info = {"buckets": len(bucketer.buckets), "late": []}
+    info = {"buckets": len(bucketer.buckets), "late": [],
+            "backend": dist.get_backend() if dist.is_initialized() else None}
     if mode == "graph":
         from video_classification_amd.graph import GraphedTrainStep
         x0, y0 = batch(rank, 0, dev)
@@ -70,12 +84,14 @@ def main():
             info["late"].append(bucketer.late)
     torch.cuda.synchronize()
     ops.check_lstm_error()
+    info["launches"] = bucketer.launches
+    info["side_stream_work"] = bool(ops.SIDE_STREAM_WORK)
     info["params"] = opt.flat.data.detach().cpu()
     info["running_mean"] = model.encoder.resnet[1].running_mean.detach().cpu()
     torch.save(info, f"{prefix}.rank{rank}.pt")
-    import torch.distributed as dist
-    dist.barrier()
-    dist.destroy_process_group()
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

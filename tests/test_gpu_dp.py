@@ -87,3 +87,42 @@ def test_two_ranks_match_single_process_sum(cuda, tmp_path, mode):
     d = (out[0]["params"] - ref_params).abs().max().item()
     assert d < 1e-2 * moved, (d, moved)             # fp32 path: summation order of the atomics (measured 3e-3)
     assert (out[0]["running_mean"] - ref_rm).abs().max().item() < 1e-5
+
+
+def _launch_one(mode, steps, prefix, **env_extra):
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("VC_DIST_BACKEND", "VC_DP_FORCE", "VC_SINGLE_DEVICE")}
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0", VC_WORKER_DET="1", **env_extra)
+    p = subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py"), mode, str(steps), prefix], env=env)
+    try:
+        assert p.wait(timeout=240) == 0
+    finally:
+        if p.poll() is None:
+            p.kill()
+    return torch.load(f"{prefix}.rank0.pt", weights_only=False)
+
+
+@pytest.mark.timeout(400)
+@pytest.mark.parametrize("mode", ["eager", "graph"])
+def test_one_rank_on_rccl_matches_plain_step(cuda, tmp_path, mode):
+    """The exchange path on its REAL backend: a one-rank RCCL ("nccl") communicator with the collectives forced on
+    (VC_DP_FORCE=1) -- ncclBroadcast of the parameters, one async ncclAllReduce per gradient bucket on the side stream
+    launched from the kernels' gradient-ready notifications (eager) or between the phase replays (graph), the stream
+    fences, the optimizer's wait.  A sum over one rank is the identity, so with ordered sums the weights must equal
+    those of the plain single-rank step bit for bit (the reference's counterpart is nn.DataParallel, train.py:515-518)."""
+    steps = 3
+    out = _launch_one(mode, steps, str(tmp_path / (mode + "_rccl")), VC_DP_FORCE="1", VC_DIST_BACKEND="nccl")
+    ref = _launch_one(mode, steps, str(tmp_path / (mode + "_plain")), VC_WORKER_PLAIN="1")
+    assert out["backend"] == "nccl" and ref["backend"] is None
+    assert out["buckets"] >= 3
+    warm = 1 if mode == "graph" else 0
+    assert out["launches"] == out["buckets"] * (steps + warm), (out["launches"], out["buckets"])
+    assert out["late"] == [0] * steps
+    assert out["side_stream_work"]
+    if mode == "graph":
+        assert out["phases"] == 4 and sum(len(b) for b in out["phase_buckets"]) == out["buckets"]
+    assert torch.equal(out["params"], ref["params"])
+    assert torch.equal(out["running_mean"], ref["running_mean"])

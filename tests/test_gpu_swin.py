@@ -246,3 +246,29 @@ def test_swin_rnn_deterministic_mode(cuda):
     for k in a:
         assert torch.isfinite(a[k]).all(), k
         assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("ws,H,shift", [(4, 8, 0), (4, 8, 2), (6, 12, 3), (7, 14, 3)])
+def test_window_attention_bf16_backward_for_small_windows(cuda, ws, H, shift):
+    """Window attention (timm WindowAttention behind model_components.py:412) with windows of 16, 36 and 49 tokens:
+    the bf16 MFMA kernels, forward and backward, against the fp32 kernels on the same (bf16-rounded) operands.  The
+    backward kernel's counted wait assumes the 24 gradient stores of a full 7 x 7 window; smaller windows issue
+    fewer and take the full wait.  Bounds: bf16 rounding of probabilities and outputs, 3e-2 relative L2."""
+    from video_classification_amd import ops
+    heads, B = 2, 3
+    C = heads * 32
+    g = torch.Generator().manual_seed(40 + ws)
+    qkv = torch.randn(B * H * H, 3 * C, generator=g).to(torch.bfloat16)
+    table = (0.5 * torch.randn((2 * ws - 1) ** 2, heads, generator=g))
+    dout = torch.randn(B * H * H, C, generator=g).to(torch.bfloat16)
+    res = {}
+    for dt in (torch.float32, torch.bfloat16):
+        q = qkv.to(cuda).to(dt).requires_grad_(True)
+        t = table.to(cuda).requires_grad_(True)
+        out = ops.window_attention(q, t, B, H, H, heads, ws, shift)
+        out.backward(dout.to(cuda).to(dt))
+        torch.cuda.synchronize()
+        res[dt] = (out.detach().float().cpu(), q.grad.float().cpu(), t.grad.float().cpu())
+    for a, b, name in zip(res[torch.bfloat16], res[torch.float32], ("out", "dqkv", "dbias")):
+        err = ((a - b).norm() / b.norm()).item()
+        assert err < 3e-2, (name, err)

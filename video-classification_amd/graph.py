@@ -25,6 +25,8 @@ class GraphedTrainStep:
     def __init__(self, model, optimizer, criterion, x_example, y_example, warmup=3, phased=True):
         self.model, self.opt, self.crit = model, optimizer, criterion
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        # gradients are exchanged between replays (more than one rank, or a forced one-rank exchange: see GradBucketer)
+        self.exchange = optimizer.bucketer is not None and optimizer.bucketer.collective
         self.x = x_example.clone()
         self.y = y_example.clone()
         model.train()
@@ -61,7 +63,7 @@ class GraphedTrainStep:
                     grad = torch.autograd.grad([self.loss], [cuts[-1]])[0]
                 else:
                     self.loss.backward()
-                    if self.world == 1:
+                    if not self.exchange:
                         self.opt.launch()
             self.graphs.append(g0)
             for k in range(len(cuts) - 1, -1, -1):
@@ -72,7 +74,7 @@ class GraphedTrainStep:
                         grad = torch.autograd.grad([cuts[k]], [cuts[k - 1]], [grad])[0]
                     else:
                         torch.autograd.backward([cuts[0]], [grad])
-                        if self.world == 1:
+                        if not self.exchange:
                             self.opt.launch()
                 self.graphs.append(gk)
             self.out = out
@@ -112,7 +114,7 @@ class GraphedTrainStep:
         if y is not self.y:
             self.y.copy_(y, non_blocking=True)
         self.opt.sync_lr()
-        b = self.opt.bucketer if self.world > 1 else None
+        b = self.opt.bucketer if self.exchange else None
         if b is not None:
             b.reset()
         for g, buckets in zip(self.graphs, self.phase_buckets):
@@ -120,9 +122,8 @@ class GraphedTrainStep:
             if b is not None:
                 for i in buckets:  # their all-reduce runs beside the next phase's replay
                     b._launch(i)
-        if self.world > 1:
-            if b is not None:
-                b.finish()
+        if self.exchange:
+            b.finish()
             self.opt.launch()
         self.opt.after_step()
         if self.correct is not None:  # the criterion reports what this replay computed

@@ -231,6 +231,10 @@ class GradBucketer:
         self.flat = flat
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # VC_DP_FORCE=1: issue the collectives even with one rank (a one-rank RCCL communicator exists), so that the
+        # side-stream all-reduces, their fences and the phased-graph interleave run on the real backend on a one-GPU box
+        self.collective = self.world > 1 or (dist.is_initialized() and os.environ.get("VC_DP_FORCE", "0") == "1")
+        self.launches = 0  # collectives issued since construction (diagnostics: bench.py reports it per rank)
         self.on_gpu = flat.grad.is_cuda
         self.overlap = overlap and self.on_gpu
         self.stream = torch.cuda.Stream() if self.overlap else None
@@ -274,8 +278,9 @@ class GradBucketer:
 
     def _launch(self, b):
         self.launched[b] = True
-        if self.world == 1:
+        if not self.collective:
             return
+        self.launches += 1
         lo, hi = self.buckets[b]
         view = self.flat.grad[lo:hi]
         if self.on_gpu and dist.get_backend(self.group) == "gloo":
@@ -320,7 +325,7 @@ def init_distributed(backend=None):
     if os.environ.get("VC_SINGLE_DEVICE", "0") == "1":
         local_rank = 0
     backend = backend or os.environ.get("VC_DIST_BACKEND") or None
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("VC_DP_FORCE", "0") == "1") and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
@@ -337,7 +342,8 @@ def make_data_parallel(model, optimizer, bucket_mb=32, group=None, overlap=True)
     state_dict keys carry no ``module.`` prefix)."""
     flat = optimizer.flat
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world > 1:
+    forced = dist.is_initialized() and os.environ.get("VC_DP_FORCE", "0") == "1"
+    if world > 1 or forced:
         dist.broadcast(flat.data, src=0, group=group)
         # buffers (BatchNorm running statistics, counters): one broadcast per dtype instead of hundreds of tiny ones
         by_dtype = {}
@@ -356,7 +362,7 @@ def make_data_parallel(model, optimizer, bucket_mb=32, group=None, overlap=True)
     optimizer.bucketer = bucketer
     optimizer.grad_scale = 1.0 / world
     ops.set_grad_ready_hook(bucketer.notify)
-    ops.SIDE_STREAM_WORK = world > 1 and bucketer.overlap
+    ops.SIDE_STREAM_WORK = bucketer.collective and bucketer.overlap
     return bucketer
 
 
