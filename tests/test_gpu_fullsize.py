@@ -11,11 +11,14 @@ every parameter gradient.  The oracle's forward + backward takes about 10 s per 
 The ResNet trunk and the Swin-T backbone restate third-party architectures (torchvision / timm are absent from the
 reference checkout and this image): these tests hold the HIP path to the oracle's restatement of them.
 
-Tolerances.  Outputs: max error relative to the largest reference logit, 2e-4 in fp32 and 4e-2 in bf16 (measured
-7e-7 / 4e-3 at worst).  Gradients: L2 error relative to the tensor's norm, bounds stated at each test from the
+Tolerances.  Outputs: max error relative to the largest reference logit, 2e-4 in fp32 and 1e-2 in bf16 (measured
+7e-7 / 3.7e-3 at worst).  Gradients: L2 error relative to the tensor's norm, bounds stated at each test from the
 measured error and the conditioning of the model (BatchNorm over few samples amplifies any rounding: the tests say
 how much the oracle's OWN gradients move when only its input is rounded to bf16).  Predictions: equal in fp32; in
-bf16 equal wherever the reference's own top-2 margin exceeds twice the output bound."""
+bf16 equal wherever the reference's own top-2 margin exceeds twice the output bound -- every test prints how many rows
+that is and requires at least half the batch (with the 1e-2 bound: 4 of 6, 6 of 6, 4 of 4 rows on these seeds).  The
+fp32 runs use ordered sums (ops.set_deterministic) and leave out, by index, the head channels whose ReLU input the
+ORACLE finds within 1e-5 of zero; everything else in the head and the decoder is held to 1e-4."""
 import functools
 import types
 
@@ -33,15 +36,25 @@ IDS = ["f32", "bf16"]
 
 NO_DROP = dict(drop_path_rate=0.0)  # stochastic depth (timm default 0.1) draws random samples: off for parity
 
-def _compare(mine, out_m, loss_m, ref_out, ref_loss, ref_grads, dt, tol_g, cancelled=(), group_tol=None):
-    tol_o = 2e-4 if dt == torch.float32 else 4e-2
+def _compare(mine, out_m, loss_m, ref_out, ref_loss, ref_grads, dt, tol_g, cancelled=(), group_tol=None, exclude=None,
+             tol_o=None, min_rows=1):
+    """`exclude` = {parameter name: indices along dim 0 left out of the comparison} (see _near_zero_relu_channels).
+    Predictions: equal in fp32; in bf16 equal on the rows whose top-2 margin in the reference exceeds twice the output
+    bound -- the number of rows compared is printed and must be at least `min_rows`."""
+    tol_o = tol_o if tol_o is not None else (2e-4 if dt == torch.float32 else 1e-2)
+    min_rows = max(min_rows, ref_out.shape[0] // 2)
     out_m = out_m.detach().float().cpu()
     err_o = G.max_rel(out_m, ref_out)
     errs = {}
     for k, p in mine.named_parameters():
         if any(k.endswith(c) for c in cancelled):
             continue
-        errs[k] = G.l2_rel(p.grad.detach().cpu(), ref_grads[k])
+        gm, gr = p.grad.detach().cpu(), ref_grads[k]
+        if exclude and k in exclude and len(exclude[k]):
+            keep = torch.ones(gm.shape[0], dtype=torch.bool)
+            keep[exclude[k]] = False
+            gm, gr = gm[keep], gr[keep]
+        errs[k] = G.l2_rel(gm, gr)
     worst = max(errs, key=errs.get)
     groups = {}
     for k, e in errs.items():
@@ -54,9 +67,13 @@ def _compare(mine, out_m, loss_m, ref_out, ref_loss, ref_grads, dt, tol_g, cance
     assert abs(loss_m - ref_loss) < (1e-4 if dt == torch.float32 else 2e-2)
     if dt == torch.float32:
         assert torch.equal(out_m.argmax(1), ref_out.argmax(1))
+        print(f"  predictions compared: all {ref_out.shape[0]} rows (fp32: every row must agree)")
     else:
         top2 = ref_out.topk(2, dim=1).values
         safe = (top2[:, 0] - top2[:, 1]) > 2 * tol_o * ref_out.abs().max()
+        print(f"  predictions compared: {int(safe.sum())} of {ref_out.shape[0]} rows (top-2 margin above twice the output bound); "
+              f"all rows agree: {bool(torch.equal(out_m.argmax(1), ref_out.argmax(1)))}")
+        assert int(safe.sum()) >= min_rows, "no row has a margin the bf16 bound can resolve: choose other weights"
         assert torch.equal(out_m.argmax(1)[safe], ref_out.argmax(1)[safe])
     assert errs[worst] < tol_g, (worst, errs[worst])
     for prefix, bound in (group_tol or {}).items():  # tighter bounds for the tensors near the loss
@@ -107,6 +124,24 @@ def _vs_emulation(mine, out, emu, rerun, cancelled=(), at_least=0.0):
     G.assert_within_noise_floor(err, floor, at_least=at_least)
 
 
+def _ordered_sums(on):
+    """Context: the device path adds in a fixed order (ops.set_deterministic), so that an fp32 comparison is not at the
+    mercy of which way the fp32 atomics' rounding pushes a ReLU input that sits at zero."""
+    import contextlib
+    from video_classification_amd import ops
+
+    @contextlib.contextmanager
+    def cm():
+        if on:
+            ops.set_deterministic(True, workspace_mb=256)
+        try:
+            yield
+        finally:
+            if on:
+                ops.set_deterministic(False)
+    return cm()
+
+
 @functools.lru_cache(maxsize=None)
 def _resnet_ref(emulate=False, arch="resnet50", layers=2, B=6):
     from oracle import torch_oracle as O
@@ -126,11 +161,38 @@ def _resnet_ref(emulate=False, arch="resnet50", layers=2, B=6):
          0.3 * torch.randn(B * 16, 3, 224, 224, generator=g)).view(B, 16, 3, 224, 224)
     y = torch.randint(0, 101, (B, 1), generator=g)
     ref.train()
+    # inputs of the head's two ReLUs (the BatchNorm1d outputs, unit scale), one call per time step: a value within 1e-5
+    # of zero may take the other branch on the device, whose trunk output differs by ~1e-6 (summation order)
+    near = {"bn1": set(), "bn2": set()}
+    hooks = [getattr(ref.encoder, n).register_forward_hook(
+        lambda m, i, o, n=n: near[n].update((o.detach().abs() < 1e-5).any(0).nonzero().flatten().tolist()))
+        for n in near]
     with _emulating(O, emulate):
         out = ref(x)
         loss = nn.CrossEntropyLoss()(out, y.squeeze(1))
         loss.backward()
+    for h in hooks:
+        h.remove()
+    _NEAR_ZERO[(emulate, arch, layers, B)] = {k: sorted(v) for k, v in near.items()}
     return cfg, ref.state_dict(), x, y, out.detach(), loss.item(), {k: p.grad for k, p in ref.named_parameters()}
+
+
+_NEAR_ZERO = {}
+
+
+def _near_zero_relu_channels(emulate=False, arch="resnet50", layers=2, B=6):
+    """{parameter: channel indices} of the head channels whose ReLU input lies within 1e-5 of zero for some sample in
+    the ORACLE's forward pass: their ReLU decision, and with it that channel's row of the fc / bn gradients, is not
+    determined at the precision two fp32 implementations agree to.  Exactly those channels are left out (and printed)."""
+    _resnet_ref(emulate, arch, layers, B)
+    nz = _NEAR_ZERO[(emulate, arch, layers, B)]
+    print(f"\n  head ReLU inputs within 1e-5 of zero in the oracle: fc1/bn1 channels {nz['bn1']}, fc2/bn2 channels {nz['bn2']}")
+    ex = {}
+    for bn, fc in (("bn1", "fc1"), ("bn2", "fc2")):
+        idx = torch.tensor(nz[bn], dtype=torch.long)
+        for k in (f"encoder.{fc}.weight", f"encoder.{bn}.weight", f"encoder.{bn}.bias"):
+            ex[k] = idx
+    return ex
 
 
 @pytest.mark.timeout(300)
@@ -145,21 +207,23 @@ def test_resnet50_crnn_ucf_shape(cuda, dt):
     from video_classification_amd import modules as M
     from video_classification_amd import ops
     cfg, sd, x, y, ref_out, ref_loss, ref_grads = _resnet_ref()
+    f32 = dt == torch.float32
     mine = M.ResNetCRNNModel(cfg)
     mine.load_state_dict(sd, strict=True)
     mine.to(cuda).set_compute_dtype(dt)
     mine.train()
-    out = mine(x.to(cuda))
-    loss = ops.cross_entropy(out, y.to(cuda))
-    loss.backward()
-    torch.cuda.synchronize()
+    with _ordered_sums(f32):
+        out = mine(x.to(cuda))
+        loss = ops.cross_entropy(out, y.to(cuda))
+        loss.backward()
+        torch.cuda.synchronize()
     ops.check_lstm_error()
-    f32 = dt == torch.float32
     # measured: fp32 trunk 7e-3, head and decoder < 1e-5; bf16 decoder.fc2 9e-3, decoder 5e-2, head 0.25, trunk 0.40
     _compare(mine, out, loss.item(), ref_out, ref_loss, ref_grads, dt, 2e-2 if f32 else 0.7,
              cancelled=["encoder.fc1.bias", "encoder.fc2.bias"],
              group_tol={"decoder.": 1e-4, "encoder.fc": 1e-4, "encoder.bn": 1e-4} if f32 else
-             {"decoder.fc2": 3e-2, "decoder.": 0.12})
+             {"decoder.fc2": 3e-2, "decoder.": 0.12},
+             exclude=_near_zero_relu_channels() if f32 else None)
     if not f32:
         e = _resnet_ref(True)
 
@@ -185,25 +249,27 @@ def test_resnet152_crnn_ucf_shape(cuda, dt):
     from video_classification_amd import modules as M
     from video_classification_amd import ops
     cfg, sd, x, y, ref_out, ref_loss, ref_grads = _resnet_ref(False, "resnet152", 3, 6)
+    f32 = dt == torch.float32
     mine = M.ResNetCRNNModel(cfg)
     mine.load_state_dict(sd, strict=True)
     mine.to(cuda).set_compute_dtype(dt)
     mine.train()
-    out = mine(x.to(cuda))
-    loss = ops.cross_entropy(out, y.to(cuda))
-    loss.backward()
-    torch.cuda.synchronize()
+    with _ordered_sums(f32):
+        out = mine(x.to(cuda))
+        loss = ops.cross_entropy(out, y.to(cuda))
+        loss.backward()
+        torch.cuda.synchronize()
     ops.check_lstm_error()
-    f32 = dt == torch.float32
-    # fp32, fc1 / bn1: one of the 96 x 1024 inputs of the head's first ReLU lies within the trunk's run-to-run noise
-    # (1e-6, the order of fp32 atomics) of zero on this seed, so its ReLU decision -- and with it the gradient of that
-    # channel -- lands on either side from run to run: 1.5e-5 when it agrees with the oracle's, 3.3e-3 when it does not
-    # (measured 4 : 6 over ten runs, the same two values every time).  Everything behind that ReLU stays below 2e-5.
+    # fp32: the device path runs with ordered sums (repeatable), and the head channels whose ReLU input lies within 1e-5
+    # of zero in the oracle -- on this seed one of the 96 x 1024 inputs of the first ReLU -- are located in the oracle
+    # and left out BY INDEX: that ReLU's decision, and with it the channel's row of the fc1 / bn1 gradients, is decided
+    # by the last bit of the trunk's output (1.5e-5 when it agrees with the oracle's, 3.3e-3 when it does not).
+    # Every other head and decoder gradient is held to 1e-4.
     _compare(mine, out, loss.item(), ref_out, ref_loss, ref_grads, dt, 2e-2 if f32 else 0.9,
              cancelled=["encoder.fc1.bias", "encoder.fc2.bias"],
-             group_tol={"decoder.": 1e-4, "encoder.fc2": 1e-4, "encoder.fc3": 1e-4, "encoder.bn2": 1e-4,
-                        "encoder.fc1": 1e-2, "encoder.bn1": 1e-2} if f32 else
-             {"decoder.fc2": 3e-2, "decoder.": 0.12})
+             group_tol={"decoder.": 1e-4, "encoder.fc": 1e-4, "encoder.bn": 1e-4} if f32 else
+             {"decoder.fc2": 3e-2, "decoder.": 0.12},
+             exclude=_near_zero_relu_channels(False, "resnet152", 3, 6) if f32 else None)
     if not f32:
         e = _resnet_ref(True, "resnet152", 3, 6)
 

@@ -224,19 +224,22 @@ def test_crnn_full_config0(cuda, dt):
     x = torch.randn(4, 16, 3, 224, 224, generator=torch.Generator().manual_seed(1234)).to(cuda)
     y = torch.from_numpy(d["in/y"]).to(cuda)
     tol_o, tol_g = TOL[dt]
-    if dt == torch.float32:
-        # The BatchNorm sums are fp32 atomics: their order, hence the last bit of the statistics, changes from
-        # run to run, and with 25 M activations in conv1 alone a few sit within that bit of a ReLU's zero.  Most
-        # runs land at 1e-5 of the reference; a flipped decision moves the first layers' gradients by up to
-        # 2.6e-3 (measured over repeated runs: 1.0e-5, 1.5e-4 or 2.6e-3, nothing in between).
-        tol_g = 5e-3
-    model.train()
-    out = model(x)
     from video_classification_amd import ops
-    stats = {}
-    loss = ops.cross_entropy(out, y, stats)
-    loss.backward()
-    torch.cuda.synchronize()
+    model.train()
+    # fp32: ordered sums (ops.set_deterministic), so that the run repeats bit for bit.  With fp32 atomics the last bit
+    # of the BatchNorm statistics changes from run to run, and with 25 M activations in conv1 alone a few sit within
+    # that bit of a ReLU's zero: runs landed at 1.0e-5, 1.5e-4 or 2.6e-3 of the reference, nothing in between.
+    if dt == torch.float32:
+        ops.set_deterministic(True, workspace_mb=256)
+    try:
+        out = model(x)
+        stats = {}
+        loss = ops.cross_entropy(out, y, stats)
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        if dt == torch.float32:
+            ops.set_deterministic(False)
     assert G.max_rel(out.detach().cpu(), d["logits"]) < tol_o
     assert abs(loss.item() - float(d["loss"])) < (1e-4 if dt == torch.float32 else 2e-2)
     if dt == torch.float32:
@@ -246,7 +249,14 @@ def test_crnn_full_config0(cuda, dt):
         # bf16: the prediction may only differ where the reference's own top-2 margin is inside the bf16 error
         ref = torch.from_numpy(d["logits"])
         top2 = ref.topk(2, dim=1).values
-        safe = (top2[:, 0] - top2[:, 1]) > 2 * tol_o * ref.abs().max()
+        # output bound 2e-2 at this shape (half the general bf16 bound): all four rows of the fixture have a top-2
+        # margin of 4.2-4.4 % of the largest logit, so every prediction is compared
+        err_o = G.max_rel(out.detach().cpu(), d["logits"])
+        print(f"\n  bf16 logits max-rel {err_o:.3e}")
+        assert err_o < 2e-2
+        safe = (top2[:, 0] - top2[:, 1]) > 2 * 2e-2 * ref.abs().max()
+        print(f"  predictions compared: {int(safe.sum())} of {ref.shape[0]} rows")
+        assert int(safe.sum()) >= ref.shape[0] // 2
         assert torch.equal(stats["pred"].cpu()[safe], ref.argmax(1)[safe])
     for k, p in model.named_parameters():
         ref = float(d[f"gnorm/{k}"])
