@@ -20,7 +20,7 @@ The JSON line also carries
                  timed region / their summed durations from HIP events on the launch stream) against the dense
                  bf16 MFMA peak of 2.5 PFLOP/s.
   cpu_baseline : the CPU oracle (oracle/torch_oracle.py, same architecture, fp32) timed on this host for a
-                 bounded sample (10 steps of 2 clips), rank 0 / N=1 only.
+                 bounded sample (5 steps of 4 clips, the configs[0] batch), rank 0 / N=1 only.
 """
 import argparse
 import json
@@ -157,8 +157,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
-    ap.add_argument("--cpu-batch", type=int, default=2)
-    ap.add_argument("--cpu-steps", type=int, default=10)
+    ap.add_argument("--cpu-batch", type=int, default=4, help="clips per CPU-baseline step (4 = the configs[0] batch)")
+    ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--bucket-mb", type=int, default=32)
     ap.add_argument("--infer", action="store_true",
                     help="time the eval-mode forward (predict.py / save_predictions callers) instead of a training step")
@@ -331,14 +331,21 @@ def main():
                       for t_, f_, _, _, b_ in prof if t_ == "conv_fwd")
         # HBM bytes per launch of the same kernel family from the PMC passes (tools/pmc_bench.sh, separate runs of
         # this command with --no-graph; FETCH_SIZE doubled as gfx950 requires) -- None if they were never collected
-        traffic, traffic_src, traffic_step = None, None, None
+        traffic, traffic_src, traffic_step, traffic_commit = None, None, None, None
         import glob
         tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_hbm_traffic.json")))  # newest file last
         tfile = tfiles[-1] if tfiles else ""
         if args.model == "resnetcrnn" and args.arch == "resnet50" and B == 32 and os.path.exists(tfile):
             with open(tfile) as fh:
                 tj = json.load(fh)
-            if "conv_fwd" in tj.get("families", {}):
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from hbm_traffic import kernel_sources_digest
+            traffic_commit = tj.get("commit")
+            if tj.get("kernel_sources_sha256") != kernel_sources_digest(ROOT):
+                # counters taken on other kernel sources than the ones this run was built from: not this run's traffic
+                traffic_src = (f"profiles/{os.path.basename(tfile)} was measured on other kernel sources (commit "
+                               f"{traffic_commit}): re-run tools/pmc_bench.sh + tools/hbm_traffic.py")
+            elif "conv_fwd" in tj.get("families", {}):
                 traffic = tj["families"]["conv_fwd"]["traffic_bytes"]
                 traffic_step = tj["families"]["conv_fwd"].get("traffic_bytes_per_step")
                 traffic_src = f"profiles/{os.path.basename(tfile)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
@@ -348,7 +355,7 @@ def main():
                 "per_launch_roofline": "sum over launches of max(flops / 2.5 PFLOP/s, algorithmic bytes / 8 TB/s) / "
                                        "measured time of the family",
                 "traffic": traffic, "traffic_unit": "bytes per launch",
-                "traffic_source": traffic_src, "traffic_bytes_per_step": traffic_step,
+                "traffic_source": traffic_src, "traffic_commit": traffic_commit, "traffic_bytes_per_step": traffic_step,
                 "algorithmic_bytes_per_launch": nb / n, "algorithmic_bytes_per_step": nb / prof_steps,
                 "launches": n, "avg_launch_ms": tm / n * 1e3, "avg_launch_gflop": fl / n / 1e9,
                 "other_kernels": {k: {"achieved_tflops": v[0] / v[1] / 1e12, "launches": v[2],

@@ -2,13 +2,20 @@
 
     python tools/hbm_traffic.py <dir with FETCH_SIZE/ and WRITE_SIZE/ csv trees> <out.json>
 
+The output records which kernels it was measured on: the SHA-256 over the library's kernel sources (the same digest
+bench.py computes at run time and compares: a traffic figure of other kernels is reported as null) and, where a git
+checkout is at hand, the commit.
+
 rocprofv3 reports both counters in KiB-like units of 1 KB = 1024 B per dispatch.  On gfx950 FETCH_SIZE tallies the
 128-byte requests of wide (16 B per lane) streaming reads at 64 bytes each, so the read bytes are 2 x FETCH_SIZE;
 WRITE_SIZE is exact for 16-byte-per-lane stores and float atomics.  traffic = 2 * FETCH_SIZE + WRITE_SIZE.
 """
 import csv
 import glob
+import hashlib
 import json
+import os
+import subprocess
 import sys
 from collections import defaultdict
 
@@ -34,10 +41,28 @@ def collect(d, counter):
     return acc
 
 
+def kernel_sources_digest(root):
+    """SHA-256 over the names and bytes of video-classification_amd/csrc/*.hip and *.h, in name order."""
+    h = hashlib.sha256()
+    src = os.path.join(root, "video-classification_amd", "csrc")
+    for name in sorted(os.listdir(src)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            with open(os.path.join(src, name), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()
+
+
 def main():
     d, out = sys.argv[1], sys.argv[2]
     fetch, write = collect(d, "FETCH_SIZE"), collect(d, "WRITE_SIZE")
-    res = {"unit": "bytes per launch (average over the launches of 3 eager steps of bench.py)",
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        commit = subprocess.run(["git", "-C", root, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    except OSError:
+        commit = None
+    res = {"kernel_sources_sha256": kernel_sources_digest(root), "commit": commit,
+           "unit": "bytes per launch (average over the launches of 3 eager steps of bench.py)",
            "correction": "read bytes = 2 x FETCH_SIZE x 1024 (gfx950 tallies 128-B requests at 64 B); write bytes = WRITE_SIZE x 1024",
            "families": {}}
     for fam in FAMILIES:

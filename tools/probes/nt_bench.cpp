@@ -55,7 +55,7 @@ int main(int argc, char** argv) {
   const int reps = getenv("NTB_REPS") ? atoi(getenv("NTB_REPS")) : 5;
   const bool naive = getenv("NTB_NAIVE") != nullptr;
   std::vector<Layer> all = {
-      {"l1b0.c2", F, 56, 56, 64, 64, 3, 1, 1},     {"l1b0.c3", F, 56, 56, 64, 256, 1, 1, 0},
+      {"l1b0.c1", F, 56, 56, 64, 64, 1, 1, 0},     {"l1b0.c2", F, 56, 56, 64, 64, 3, 1, 1},     {"l1b0.c3", F, 56, 56, 64, 256, 1, 1, 0},
       {"l1b1.c1", F, 56, 56, 256, 64, 1, 1, 0},    {"l2b0.c1", F, 56, 56, 256, 128, 1, 1, 0},
       {"l2b0.c3", F, 28, 28, 128, 512, 1, 1, 0},   {"l2b1.c1", F, 28, 28, 512, 128, 1, 1, 0},
       {"l2b1.c2", F, 28, 28, 128, 128, 3, 1, 1},   {"l3b0.c1", F, 28, 28, 512, 256, 1, 1, 0},
@@ -96,10 +96,10 @@ int main(int argc, char** argv) {
       for (int variant = 0; variant < 2; ++variant) {
         setenv("VC_NT8", variant == 0 ? "1" : "0", 1);
         uint16_t* o = pass == 0 ? (variant == 0 ? y0 : y1) : (variant == 0 ? dx0 : dx1);
-        HIP(hipMemset(o, 0xFF, (pass == 0 ? ny : nx) * 2));
+        HIP(hipMemset(o, getenv("NTB_BETA") ? 0 : 0xFF, (pass == 0 ? ny : nx) * 2));
         auto run = [&]() {
           int rc = pass == 0 ? vc_conv_fwd(desc, 1, x, 0, wf, nullptr, o, 0, 0, 0, 0, nullptr)
-                             : vc_conv_dgrad(desc, 1, dy, 0, wt, o, 0, 0, 0, nullptr);
+                             : vc_conv_dgrad(desc, 1, dy, 0, wt, o, 0, 0, getenv("NTB_BETA") ? 1 : 0, nullptr);
           if (rc) { printf("%s failed: %s\n", l.name, vc_last_error()); exit(3); }
         };
         run();
