@@ -47,7 +47,7 @@ __global__ __launch_bounds__(NW * 64) void dma_kernel(const char* __restrict__ t
 }
 
 // the staging pattern of a phased GEMM loop: NP pieces per wave, a counted wait, NB barriers, repeat
-template <int NP, int NB, int WAITN, int LGKM = 0>
+template <int NP, int NB, int WAITN, int LGKM = 0, int SAME = 0>
 __global__ __launch_bounds__(512) void dma_phase_kernel(const char* __restrict__ tab, size_t tab_bytes, int stride, int iters) {
   __shared__ __attribute__((aligned(1024))) char smem[128 * 1024];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -56,7 +56,11 @@ __global__ __launch_bounds__(512) void dma_phase_kernel(const char* __restrict__
   const size_t lane_off = (size_t)r * stride + (((lane & 7) ^ (r & 7)) * 16);
   const int piece_adv = 8 * stride;
   const size_t span = tab_bytes / 2;
-  size_t pos = ((size_t)(blockIdx.x * 8 + wave) * 37 * piece_adv) % span;
+  // SAME 1: every workgroup walks the same addresses at the same time (a weight tile shared by all CUs);
+  // SAME 2: the same addresses, each workgroup starting at its own offset into the walk
+  size_t pos = SAME == 1 ? ((size_t)wave * piece_adv) % span
+             : SAME == 2 ? ((size_t)(wave + 8 * (blockIdx.x * 13 % 64)) * piece_adv) % span
+                         : ((size_t)(blockIdx.x * 8 + wave) * 37 * piece_adv) % span;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(tab), 0, (int)tab_bytes, 0x00020000);
   char* dst = smem + wave * 16384;
   int slot = 0;
@@ -131,17 +135,17 @@ void run_pingpong(const char* tab, size_t tab_bytes, int stride) {
          bytes_cu / ms / 1e6, ms * 1e6 / iters);
 }
 
-template <int NP, int NB, int WAITN, int LGKM = 0>
+template <int NP, int NB, int WAITN, int LGKM = 0, int SAME = 0>
 void run_phase(const char* tab, size_t tab_bytes, int stride) {
   const int iters = 8000;
   hipEvent_t e0, e1; HIP(hipEventCreate(&e0)); HIP(hipEventCreate(&e1));
-  dma_phase_kernel<NP, NB, WAITN, LGKM><<<256, 512>>>(tab, tab_bytes, stride, 50);
+  dma_phase_kernel<NP, NB, WAITN, LGKM, SAME><<<256, 512>>>(tab, tab_bytes, stride, 50);
   HIP(hipEventRecord(e0));
-  dma_phase_kernel<NP, NB, WAITN, LGKM><<<256, 512>>>(tab, tab_bytes, stride, iters);
+  dma_phase_kernel<NP, NB, WAITN, LGKM, SAME><<<256, 512>>>(tab, tab_bytes, stride, iters);
   HIP(hipEventRecord(e1)); HIP(hipEventSynchronize(e1));
   float ms; HIP(hipEventElapsedTime(&ms, e0, e1));
   const double bytes_cu = (double)iters * NP * 1024 * 8;
-  printf("phased (lgkm wait %d): %d pieces / wave, vmcnt(%2d), %d barriers, table %4zu MiB: %7.1f GB/s per CU, %5.1f B/clk, %6.0f ns per iteration\n", LGKM, NP, WAITN, NB,
+  printf("phased (lgkm wait %d, same-address mode %d): %d pieces / wave, vmcnt(%2d), %d barriers, table %4zu MiB: %7.1f GB/s per CU, %5.1f B/clk, %6.0f ns per iteration\n", LGKM, SAME, NP, WAITN, NB,
          tab_bytes >> 20, bytes_cu / ms / 1e6, bytes_cu / (ms * 1e-3) / 2.4e9, ms * 1e6 / iters);
 }
 
@@ -229,6 +233,11 @@ int main() {
   run<2, 1, 8>("8 rows x 128 B, chunks XOR-permuted", tab, tab_bytes, 4608, 8);
   run<3, 1, 8>("16 rows x 64 B", tab, tab_bytes, 512, 8);
   run<4, 1, 8>("64 rows x 16 B", tab, tab_bytes, 512, 8);
+  run_phase<2, 2, 8, 0, 1>(tab, tab_bytes, 512);
+  run_phase<2, 2, 8, 0, 2>(tab, tab_bytes, 512);
+  run_phase<2, 2, 8, 0, 1>(tab, tab_bytes, 4608);
+  run_phase<2, 2, 8, 0, 2>(tab, tab_bytes, 4608);
+  run_phase<8, 2, 8, 0, 1>(tab, tab_bytes, 4608);
   run_pingpong<2, 0>(tab, tab_bytes, 512);
   run_pingpong<2, 64>(tab, tab_bytes, 512);
   run_pingpong<1, 64>(tab, tab_bytes, 512);

@@ -106,7 +106,7 @@ int main(int argc, char** argv) {
         HIP(hipDeviceSynchronize());
         float tot = 0;
         for (int r = 0; r < reps; ++r) {
-          HIP(hipMemsetAsync(flush, r, flush_bytes, nullptr));
+          if (!getenv("NTB_NOFLUSH")) HIP(hipMemsetAsync(flush, r, flush_bytes, nullptr));
           HIP(hipEventRecord(e0, nullptr));
           run();
           HIP(hipEventRecord(e1, nullptr));
