@@ -1456,7 +1456,7 @@ int launch_nt(const ConvGeom& g, int dtype, const void* src, const void* wgt, co
   if (dtype == VC_BF16) {
     VC_CHECK_SHAPE(g.Ci % 8 == 0, "%s: bf16 path needs source channels %% 8 == 0 (got %d)", who, g.Ci);
     const int tiles = ceil_div(g.M, BM) * ceil_div(g.Co, BN);
-    if (nt_persist_eligible(g, dtype) && MODE != 2 && vc_nt8_eligible(g, MODE, out_f32)) {
+    if (nt_persist_eligible(g, dtype) && MODE != 2 && vc_nt8_eligible(g, MODE, out_f32, EPI_NONE)) {
       vc_nt8_launch(g, MODE, EPI_NONE, stream, src, wgt, bias, out, relu, beta, bn_partial, nullptr, nullptr);
     } else if (nt_persist_eligible(g, dtype)) {
       if (g.Co <= nt_narrow()) {  // a 128-wide channel tile would be half padding
@@ -1632,6 +1632,11 @@ int vc_conv_dgrad_bn_tail(const int* desc, int dtype, const void* dy, const void
   VC_CHECK_ARG(dy && w_packed_t && dx && tail_y && tail_bits && bn_partial, "vc_conv_dgrad_bn_tail: null pointer");
   VC_CHECK_SHAPE(dgrad_tail_eligible(g, dtype),
                  "vc_conv_dgrad_bn_tail: unsupported geometry (ask vc_conv_dgrad_bn_tail_supported)");
+  if (vc_nt8_eligible(g, 1, 0, EPI_BN_TAIL)) {
+    vc_nt8_launch(g, 1, EPI_BN_TAIL, stream, dy, w_packed_t, nullptr, dx, 0, beta, bn_partial, tail_y, tail_bits);
+    VC_LAUNCH_CHECK("vc_conv_dgrad_bn_tail");
+    return VC_OK;
+  }
   const int tiles = ceil_div(g.M, BM) * ceil_div(g.Co, BN);
   const int grid = tiles < nt_persist_blocks() ? tiles : nt_persist_blocks();
   launch_persist<1, 128, EPI_BN_TAIL>(g, grid, stream, dy, w_packed_t, nullptr, dx, 0, 0, beta, tiles, bn_partial, tail_y,
@@ -1660,7 +1665,9 @@ int vc_conv_dgrad_bn_pre(const int* desc, int dtype, const void* dy, const void*
   VC_CHECK_ARG(dy && w_packed_t && dx && y && stat && bn_partial, "vc_conv_dgrad_bn_pre: null pointer");
   VC_CHECK_SHAPE(vc_conv_dgrad_bn_pre_supported(desc, dtype, rows_per_group) == 1,
                  "vc_conv_dgrad_bn_pre: unsupported geometry (ask vc_conv_dgrad_bn_pre_supported)");
-  if (g.Co <= nt_narrow()) {
+  if (vc_nt8_eligible(g, 1, 0, EPI_BN_PRE)) {
+    vc_nt8_launch(g, 1, EPI_BN_PRE, stream, dy, w_packed_t, stat, dx, rows_per_group, 0, bn_partial, y, nullptr);
+  } else if (g.Co <= nt_narrow()) {
     const int t64 = ceil_div(g.M, BM) * ceil_div(g.Co, 64);
     const int grid = t64 < nt_persist_blocks() * 3 / 2 ? t64 : nt_persist_blocks() * 3 / 2;
     launch_persist<1, 64, EPI_BN_PRE>(g, grid, stream, dy, w_packed_t, stat, dx, rows_per_group, 0, 0, t64, bn_partial,

@@ -449,7 +449,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 // 256 x 256-tile, 8-wave form of the NT kernel (vc_igemm8.hip).  `mode` 0 forward, 1 data gradient, 2 one output phase of
 // a strided data gradient; `epi` one of the EPI_* constants; bf16 output only.
-bool vc_nt8_eligible(const ConvGeom& g, int mode, int out_f32);
+bool vc_nt8_eligible(const ConvGeom& g, int mode, int out_f32, int epi);
 void vc_nt8_launch(const ConvGeom& g, int mode, int epi, hipStream_t stream, const void* src, const void* wgt,
                    const float* bias, void* out, int relu, int beta, float* bn_partial, const void* tail_y,
                    const uint8_t* tail_bits);
