@@ -167,3 +167,67 @@ def test_wide_kernel_repeats_bit_identically(cuda):
             L.call("vc_conv_fwd", d, 1, L.ptr(x), 0, L.ptr(wf), L.ptr(None), L.ptr(y), 0, 0, 0, 0, L.stream())
             torch.cuda.synchronize()
             assert torch.equal(y, ref)
+
+
+class _WideW(_Wide):
+    def __enter__(self):
+        self.old = os.environ.get("VC_WGRAD8")
+        os.environ["VC_WGRAD8"] = "1" if self.on else "0"
+
+    def __exit__(self, *a):
+        if self.old is None:
+            del os.environ["VC_WGRAD8"]
+        else:
+            os.environ["VC_WGRAD8"] = self.old
+
+
+WSHAPES = [
+    # N, H, W, Ci, Co, k, s: ragged everything / channel tail, one tap / strided 3x3 / many slices / a narrow layer
+    (3, 13, 11, 192, 320, 3, 1),
+    (5, 9, 7, 136, 200, 1, 1),
+    (8, 28, 28, 256, 256, 3, 2),
+    (64, 14, 14, 256, 1024, 1, 1),
+    (4, 56, 56, 64, 64, 3, 1),
+]
+
+
+@pytest.mark.parametrize("shape", WSHAPES, ids=["x".join(map(str, s)) for s in WSHAPES])
+@pytest.mark.parametrize("det", [False, True], ids=["atomics", "ordered"])
+def test_weight_gradient_on_wide_tiles(cuda, shape, det):
+    """The 256 x 256-tile weight-gradient kernel (csrc/vc_wgrad8.hip) against the plain-FMA kernel on the same bf16 data
+    (fp32 sums in a different order: 2e-4 of the largest magnitude, the bound of the 128-wide kernel's test), with the
+    bias gradient, and in deterministic mode (slices added in order): two runs bit-identical."""
+    from video_classification_amd import _lib as L
+    from video_classification_amd import ops
+    N, H, W, Ci, Co, k, s = shape
+    g = torch.Generator().manual_seed(41)
+    p = k // 2
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    x = torch.randn(N * H * W, Ci, generator=g).to(cuda, torch.bfloat16)
+    dy = torch.randn(N * Ho * Wo, Co, generator=g).to(cuda, torch.bfloat16)
+    d = L.int_array([N, 1, H, W, Ci, 1, Ho, Wo, Co, 1, k, k, 1, s, s, 0, p, p])
+    dwn = torch.zeros(Co, k * k, Ci, device=cuda)
+    L.call("vc_conv_wgrad", d, 1, L.ptr(x), 0, L.ptr(dy), 0, L.ptr(dwn), L.ptr(None), 1, L.stream())
+    torch.cuda.synchronize()
+    runs = []
+    with _WideW(1):
+        ops.set_deterministic(det)
+        try:
+            for _ in range(2):
+                dw = torch.zeros(Co, k * k, Ci, device=cuda)
+                db = torch.zeros(Co, device=cuda)
+                L.call("vc_conv_wgrad", d, 1, L.ptr(x), 0, L.ptr(dy), 0, L.ptr(dw), L.ptr(db), 0, L.stream())
+                torch.cuda.synchronize()
+                runs.append((dw, db))
+        finally:
+            ops.set_deterministic(False)
+    assert _rel(runs[0][0], dwn) < 2e-4
+    assert _rel(runs[0][1], dy.float().sum(0)) < 2e-4
+    if det:
+        assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    # accumulation into a non-zero dw
+    with _WideW(1):
+        dw = torch.ones(Co, k * k, Ci, device=cuda)
+        L.call("vc_conv_wgrad", d, 1, L.ptr(x), 0, L.ptr(dy), 0, L.ptr(dw), L.ptr(None), 0, L.stream())
+        torch.cuda.synchronize()
+    assert _rel(dw - 1, dwn) < 2e-4

@@ -1,9 +1,10 @@
-// Stand-alone A/B bench of the NT implicit-GEMM kernels through the C ABI of libvc_hip.so (no Python, no torch):
-// every layer is run with the 8-wave 256-wide kernel (VC_NT8=1) and the 4-wave 128-wide one (VC_NT8=0), outputs are
-// compared with each other and (optionally) with the plain-FMA kernel, and each launch is timed with HIP events on
-// cold operands (a 1 GiB fill runs before every timed launch).
-//   hipcc -O2 --offload-arch=gfx950 tools/probes/nt_bench.cpp -o gpurun_out/nt_bench -Lvideo-classification_amd -lvc_hip
-//   LD_LIBRARY_PATH=video-classification_amd gpurun_out/nt_bench [layer-name-substring ...]
+// Stand-alone A/B bench of the implicit-GEMM kernels through the C ABI of libvc_hip.so (no Python, no torch):
+// every layer is run with the 8-wave 256-wide kernels (VC_NT8=1 / VC_WGRAD8=1) and the 4-wave 128-wide ones (=0), outputs
+// are compared with each other and (NTB_NAIVE=1) with the plain-FMA kernels, and each launch is timed with HIP events on
+// cold operands (a 1 GiB fill runs before every timed launch).  NTB_PASS selects 0 forward, 1 data gradient, 2 weight
+// gradient (default: all three).
+//   hipcc -O2 --offload-arch=gfx950 tools/probes/nt_bench.cpp -o tools/probes/nt_bench.bin -Lvideo-classification_amd -lvc_hip
+//   LD_LIBRARY_PATH=video-classification_amd tools/probes/nt_bench.bin [layer-name-substring ...]
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -43,6 +44,17 @@ __global__ void diff_bf16_f32(const uint16_t* a, const float* b, size_t n, float
     md = fmaxf(md, fabsf(x - y));
     ma = fmaxf(ma, fabsf(y));
     if (!(x == x)) md = 1e30f;
+  }
+  atomicMax(reinterpret_cast<int*>(out), __float_as_int(md));
+  atomicMax(reinterpret_cast<int*>(out) + 1, __float_as_int(ma));
+}
+
+__global__ void diff_f32(const float* a, const float* b, size_t n, float* out) {
+  float md = 0.f, ma = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    md = fmaxf(md, fabsf(a[i] - b[i]));
+    ma = fmaxf(ma, fabsf(b[i]));
+    if (!(a[i] == a[i])) md = 1e30f;
   }
   atomicMax(reinterpret_cast<int*>(out), __float_as_int(md));
   atomicMax(reinterpret_cast<int*>(out) + 1, __float_as_int(ma));
@@ -131,53 +143,47 @@ int main(int argc, char** argv) {
              ms[0], gf / ms[0], ms[1], gf / ms[1], d[0] / (d[1] > 0 ? d[1] : 1), dn[0] / (dn[1] > 0 ? dn[1] : 1));
       fflush(stdout);
     }
-    if (getenv("NTB_CLOCK")) {  // in-kernel clock of the diagnostic builds (VC_NT8_VAR = 2048 + ablation bits)
-      unsigned long long* dbg; HIP(hipMalloc(&dbg, 256 * 8 * 4 * 8));
-      char buf[32]; snprintf(buf, sizeof buf, "%llx", (unsigned long long)dbg);
-      setenv("VC_NT8_DBG", buf, 1); setenv("VC_NT8", "1", 1);
-      const int vars[] = {2048, 2049, 2050, 2051, 2064, 2304};
-      for (int v : vars) {
-        char vb[16]; snprintf(vb, sizeof vb, "%d", v); setenv("VC_NT8_VAR", vb, 1);
-        HIP(hipMemset(dbg, 0, 256 * 8 * 4 * 8));
+    if (!getenv("NTB_PASS") || atoi(getenv("NTB_PASS")) == 2) {  // weight gradient: 256-wide tiles against 128-wide
+      float *dw0, *dw1, *dwn; float ms[2] = {0, 0};
+      HIP(hipMalloc(&dw0, nw * 4)); HIP(hipMalloc(&dw1, nw * 4)); HIP(hipMalloc(&dwn, nw * 4));
+      for (int variant = 0; variant < 2; ++variant) {
+        setenv("VC_WGRAD8", variant == 0 ? "1" : "0", 1);
+        float* o = variant == 0 ? dw0 : dw1;
+        auto run = [&]() {
+          int rc = vc_conv_wgrad(desc, 1, x, 0, dy, 0, o, nullptr, 0, nullptr);
+          if (rc) { printf("%s wgrad failed: %s\n", l.name, vc_last_error()); exit(3); }
+        };
+        run();
+        HIP(hipDeviceSynchronize());
         float tot = 0;
-        for (int r = 0; r < 20; ++r) {  // back-to-back launches: the clock settles under load
+        for (int r = 0; r < reps; ++r) {
+          if (!getenv("NTB_NOFLUSH")) HIP(hipMemsetAsync(flush, r, flush_bytes, nullptr));
+          if (r == reps - 1) HIP(hipMemsetAsync(o, 0, nw * 4, nullptr));  // the last launch's sum is the one compared
           HIP(hipEventRecord(e0, nullptr));
-          int rc = vc_conv_fwd(desc, 1, x, 0, wf, nullptr, y0, 0, 0, 0, 0, nullptr);
-          if (rc) { printf("clock run failed: %s\n", vc_last_error()); exit(3); }
+          run();
           HIP(hipEventRecord(e1, nullptr));
+          HIP(hipEventSynchronize(e1));
+          float t; HIP(hipEventElapsedTime(&t, e0, e1)); tot += t;
         }
-        HIP(hipEventSynchronize(e1)); HIP(hipEventElapsedTime(&tot, e0, e1));
-        std::vector<unsigned long long> h(256 * 8 * 4); HIP(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
-        double ck = 0, rt = 0; int n = 0;
-        for (int b = 0; b < 256; ++b) { if (h[b * 32 + 1]) { ck += h[b * 32]; rt += h[b * 32 + 1]; ++n; } }
-        printf("  var %4d (bits: 1 no staging, 2 no fragment reads, 16 no products, 256 free-running): last launch %.3f ms, in-kernel clock %.2f GHz, loop %.0f kcycles\n",
-               v & ~2048, tot, n ? ck / rt * 0.1 : 0.0, n ? ck / n / 1e3 : 0.0);
+        ms[variant] = tot / reps;
       }
-      unsetenv("VC_NT8_VAR");
-      (void)hipFree(dbg);
-    }
-    if (getenv("NTB_PROF")) {  // cycle stamps of the diagnostic build (VC_NT8_VAR=64): averages per wave row
-      unsigned* dbg; HIP(hipMalloc(&dbg, 256 * 8 * 8 * 4)); HIP(hipMemset(dbg, 0, 256 * 8 * 8 * 4));
-      char buf[32]; snprintf(buf, sizeof buf, "%llx", (unsigned long long)dbg);
-      setenv("VC_NT8_DBG", buf, 1); setenv("VC_NT8_VAR", "64", 1); setenv("VC_NT8", "1", 1);
-      HIP(hipMemsetAsync(flush, 1, flush_bytes, nullptr));
-      int rc = vc_conv_fwd(desc, 1, x, 0, wf, nullptr, y0, 0, 0, 0, 0, nullptr);
-      if (rc) { printf("prof failed: %s\n", vc_last_error()); exit(3); }
-      HIP(hipDeviceSynchronize());
-      std::vector<unsigned> h(256 * 8 * 8); HIP(hipMemcpy(h.data(), dbg, h.size() * 4, hipMemcpyDeviceToHost));
-      for (int grp = 0; grp < 2; ++grp) {
-        double a[7] = {0, 0, 0, 0, 0, 0, 0}; int cnt = 0;
-        for (int b = 0; b < 256; ++b) for (int w = grp * 4; w < grp * 4 + 4; ++w) {
-          const unsigned* d = &h[(b * 8 + w) * 8];
-          if (!d[5]) continue;
-          for (int i = 0; i < 5; ++i) a[i] += (double)d[i] / d[5];
-          a[5] += d[5]; a[6] += d[6]; ++cnt;
-        }
-        if (cnt) printf("  prof wave row %d: per phase cycles: issue %.0f  vmwait %.0f  barrier1+lgkm %.0f  mfma %.0f  barrier2 %.0f | phases %.0f  epilogue cycles total %.0f\n",
-                        grp, a[0] / cnt, a[1] / cnt, a[2] / cnt, a[3] / cnt, a[4] / cnt, a[5] / cnt, a[6] / cnt);
+      unsetenv("VC_WGRAD8");
+      HIP(hipMemset(dstat, 0, 8));
+      diff_f32<<<1024, 256>>>(dw0, dw1, nw, dstat);
+      float d[2]; HIP(hipMemcpy(d, dstat, 8, hipMemcpyDeviceToHost));
+      float dn[2] = {0, 1};
+      if (naive) {
+        HIP(hipMemset(dwn, 0, nw * 4));
+        int rc = vc_conv_wgrad(desc, 1, x, 0, dy, 0, dwn, nullptr, 1, nullptr);
+        if (rc) { printf("naive wgrad failed: %s\n", vc_last_error()); exit(3); }
+        HIP(hipMemset(dstat, 0, 8));
+        diff_f32<<<1024, 256>>>(dw0, dwn, nw, dstat);
+        HIP(hipMemcpy(dn, dstat, 8, hipMemcpyDeviceToHost));
       }
-      unsetenv("VC_NT8_VAR");
-      (void)hipFree(dbg);
+      printf("%-10s %-28s %8.1f | %-7s %8.3f %8.0f | %8.3f %8.0f | %9.2e %9.2e\n", l.name, shape, gf, "wgrad", ms[0], gf / ms[0],
+             ms[1], gf / ms[1], d[0] / (d[1] > 0 ? d[1] : 1), dn[0] / (dn[1] > 0 ? dn[1] : 1));
+      fflush(stdout);
+      (void)hipFree(dw0); (void)hipFree(dw1); (void)hipFree(dwn);
     }
     (void)hipFree(x); (void)hipFree(dy); (void)hipFree(wf); (void)hipFree(wt); (void)hipFree(y0); (void)hipFree(y1); (void)hipFree(dx0); (void)hipFree(dx1); (void)hipFree(yn);
   }

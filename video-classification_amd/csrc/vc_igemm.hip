@@ -1778,6 +1778,24 @@ int vc_conv_wgrad(const int* desc, int dtype, const void* x, int ldx, const void
   if (dtype == VC_BF16 && !force_naive) {
     VC_CHECK_SHAPE(g.Ci % 8 == 0 && g.Co % 8 == 0, "vc_conv_wgrad: bf16 path needs Ci %% 8 == 0 and Co %% 8 == 0");
     const bool fast = use_glds() && !use_generic_nt();
+    if (fast && vc_wgrad8_eligible(g, ldy_)) {  // wide layers: 256 x 256 tiles, one workgroup per CU
+      const size_t nw = (size_t)g.Co * g.K;
+      const bool det = vc_deterministic();
+      int splits, mps;
+      vc_wgrad8_plan(g, vc_det_capacity(), det, &splits, &mps);
+      const bool ordered = det && splits > 1;
+      float* target = dw_packed;
+      if (ordered) {
+        target = vc_det_workspace((size_t)splits * nw, stream, "vc_conv_wgrad");
+        if (!target) return VC_ERR_ARG;
+      }
+      vc_wgrad8_launch(g, x, dy, ldy_, target, splits, mps, ordered ? nw : 0, stream);
+      VC_LAUNCH_CHECK("vc_conv_wgrad");
+      if (ordered)
+        if (int rc2 = vc_det_reduce(dw_packed, target, nw, splits, stream)) return rc2;
+      if (dbias) return vc_colsum(dtype, dy, dbias, g.M, g.Co, ldy_, stream);
+      return VC_OK;
+    }
     float* dbias_fused = fast ? dbias : nullptr;
     int tco = (fast && g.Co <= 64 && wgrad_narrow()) ? 64 : 128;
     int tcol = (fast && g.K <= 64 && wgrad_narrow()) ? 64 : 128;

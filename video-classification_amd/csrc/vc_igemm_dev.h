@@ -453,3 +453,11 @@ bool vc_nt8_eligible(const ConvGeom& g, int mode, int out_f32, int epi);
 void vc_nt8_launch(const ConvGeom& g, int mode, int epi, hipStream_t stream, const void* src, const void* wgt,
                    const float* bias, void* out, int relu, int beta, float* bn_partial, const void* tail_y,
                    const uint8_t* tail_bits);
+
+// 256 x 256-tile, 8-wave form of the weight-gradient kernel (vc_wgrad8.hip): bf16, no fused bias gradient.
+// vc_wgrad8_plan chooses the slices of the pixel rows (m_per_split a multiple of 64); the slices are added with float
+// atomics into dw, or into copies `split_stride` floats apart when that is not zero.
+bool vc_wgrad8_eligible(const ConvGeom& g, int ldy);
+void vc_wgrad8_plan(const ConvGeom& g, size_t det_capacity, bool det, int* splits, int* m_per_split);
+void vc_wgrad8_launch(const ConvGeom& g, const void* x, const void* dy, int ldy, float* dw, int splits, int m_per_split,
+                      size_t split_stride, hipStream_t stream);
