@@ -182,12 +182,17 @@ class _WideW(_Wide):
 
 
 WSHAPES = [
-    # N, H, W, Ci, Co, k, s: ragged everything / channel tail, one tap / strided 3x3 / many slices / a narrow layer
+    # N, H, W, Ci, Co, k, s: ragged everything / channel tail, one tap / strided 3x3 / many slices, then the narrow tiles:
+    # 64 x 256 (3x3, 64 channels) / 256 x 64 / 64 x 256 (1x1) / 128 x 256 / 256 x 128
     (3, 13, 11, 192, 320, 3, 1),
     (5, 9, 7, 136, 200, 1, 1),
     (8, 28, 28, 256, 256, 3, 2),
     (64, 14, 14, 256, 1024, 1, 1),
     (4, 56, 56, 64, 64, 3, 1),
+    (3, 31, 29, 64, 256, 1, 1),
+    (3, 31, 29, 256, 64, 1, 1),
+    (5, 28, 28, 128, 128, 3, 1),
+    (7, 28, 27, 128, 512, 1, 1),
 ]
 
 
