@@ -455,7 +455,8 @@ void vc_nt8_launch(const ConvGeom& g, int mode, int epi, hipStream_t stream, con
                    const uint8_t* tail_bits);
 
 // 256 x 256-tile, 8-wave form of the weight-gradient kernel (vc_wgrad8.hip): bf16, no fused bias gradient.
-// vc_wgrad8_plan chooses the slices of the pixel rows (m_per_split a multiple of 64); the slices are added with float
+// vc_wgrad8_plan chooses the slices of the pixel rows (m_per_split a multiple of 64, or 0: slice s works k-tiles s,
+// s + splits, ... of 64 rows); the slices are added with float
 // atomics into dw, or into copies `split_stride` floats apart when that is not zero.
 bool vc_wgrad8_eligible(const ConvGeom& g, int ldy);
 void vc_wgrad8_plan(const ConvGeom& g, size_t det_capacity, bool det, int* splits, int* m_per_split);

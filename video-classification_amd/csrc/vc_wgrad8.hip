@@ -88,9 +88,16 @@ __global__ __launch_bounds__(NW8, 2) void igemm_tn_wgrad8_kernel(ConvGeom g, con
   if (split_stride) dw += (size_t)split * split_stride;  // deterministic mode: one copy of dw per slice
   const int tile_co = tile / tiles_col, tile_col = tile - tile_co * tiles_col;
   const int co0 = tile_co * TCO, col0 = tile_col * TCOL;
-  const int m_begin = split * m_per_split;
-  const int m_end = min(g.M, m_begin + m_per_split);
-  const int nkt = m_begin < m_end ? (m_end - m_begin + RB - 1) / RB : 0;
+  // m_per_split > 0: slice `split` is the contiguous row range [split * m_per_split, ...); m_per_split == 0: the slices
+  // are interleaved, slice `split` works k-tiles split, split + S, split + 2 S, ... of the whole matrix
+  const bool il = m_per_split == 0;
+  const int nsplit = gridDim.x / ntiles;
+  const int kstep = il ? nsplit : 1;
+  const int m_begin = il ? split * RB : split * m_per_split;
+  const int m_end = il ? g.M : min(g.M, m_begin + m_per_split);
+  const int total_kt = (g.M + RB - 1) / RB;
+  const int nkt = il ? (split < total_kt ? (total_kt - split + nsplit - 1) / nsplit : 0)
+                     : (m_begin < m_end ? (m_end - m_begin + RB - 1) / RB : 0);
 
   // staging roles: request q of a wave covers rows (8 q + wave) RPR + (0 .. RPR-1); lane -> row lr of those, 16-byte
   // piece pc of the row.  The block swizzle of a lane's row does not depend on q (rows 8 RPR >= 16 apart), so the
@@ -115,7 +122,7 @@ __global__ __launch_bounds__(NW8, 2) void igemm_tn_wgrad8_kernel(ConvGeom g, con
   const unsigned yvo = covalid ? (unsigned)(((m_begin + ysrow) * ldy + co0 + ychunk * 8) * 2) : SENT;
 
   auto decode_rows = [&](int kt, int t) {  // row t of k-tile kt into table kt & 1 (read by that k-tile's requests)
-    const int m = m_begin + kt * RB + t;
+    const int m = m_begin + kt * kstep * RB + t;
     RowOrigin ri;
     ri.off = 0;
     ri.d0 = ri.w0 = 0;
@@ -135,7 +142,7 @@ __global__ __launch_bounds__(NW8, 2) void igemm_tn_wgrad8_kernel(ConvGeom g, con
     if (p < NPY) {
       // (the whole offset goes into the lane register: only that one is certain to be range-checked)
       wdma16(rs_y, wlds_addr(sY + (p * 8 + wave) * RPRY * TCO),
-             yvo == SENT ? SENT : yvo + (unsigned)((kt * RB + p * 8 * RPRY) * ldy * 2), 0);
+             yvo == SENT ? SENT : yvo + (unsigned)((kt * kstep * RB + p * 8 * RPRY) * ldy * 2), 0);
     } else {
       const int q = p - NPY;
       const int4 ri = *reinterpret_cast<const int4*>(&rinfo[kt & 1][q * 8 * RPRX + xsrow]);
@@ -286,7 +293,7 @@ bool vc_wgrad8_eligible(const ConvGeom& g, int ldy) {
   return policy == 1 || !(tco == 64 && g.kd * g.kh * g.kw > 1);
 }
 
-// splits: slices of the pixel rows; m_per_split a multiple of 64.  One workgroup per CU and launch where the layer
+// splits: slices of the pixel rows; m_per_split a multiple of 64, or 0 for interleaved slices.  One workgroup per CU and launch where the layer
 // allows; never fewer than 512 rows per slice (the fp32 tile a slice adds costs as much as ~100 rows of products).
 void vc_wgrad8_plan(const ConvGeom& g, size_t det_capacity, bool det, int* splits, int* m_per_split) {
   int tco, tcol;
@@ -303,8 +310,12 @@ void vc_wgrad8_plan(const ConvGeom& g, size_t det_capacity, bool det, int* split
     if (s < 1) s = 1;
   }
   const int mps = ceil_div(ceil_div(g.M, s), RB) * RB;
-  *m_per_split = mps;
   *splits = ceil_div(g.M, mps);
+  // Interleaved slices by default: the workgroups then read one moving window of the two tensors together instead of
+  // 256 streams megabytes apart (the layers bound by memory run 7 % faster: 0.239 -> 0.222 ms on 56 x 56 x 64 -> 256).
+  // VC_WGRAD8_IL=0 gives every slice one contiguous row range.
+  const char* e = getenv("VC_WGRAD8_IL");
+  *m_per_split = (e && !atoi(e)) ? mps : 0;
 }
 
 void vc_wgrad8_launch(const ConvGeom& g, const void* x, const void* dy, int ldy, float* dw, int splits, int m_per_split,
