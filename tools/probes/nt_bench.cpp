@@ -79,10 +79,22 @@ int main(int argc, char** argv) {
       {"l4b1.c2", F, 7, 7, 512, 512, 3, 1, 1},     {"gemm4k", 1, 1, 4096, 4096, 4096, 1, 1, 0},
       {"gemm8k", 1, 1, 8192, 8192, 8192, 1, 1, 0}, {"odd", 3, 13, 11, 192, 320, 3, 1, 1},
       {"odd1", 5, 9, 7, 136, 200, 1, 1, 0},
+      // Swin-T linear layers at 8 clips x 16 frames (tokens per frame 3136 / 784 / 196 / 49): qkv, proj, fc1, fc2
+      {"sw1.qkv", 128, 56, 56, 96, 288, 1, 1, 0},   {"sw1.proj", 128, 56, 56, 96, 96, 1, 1, 0},
+      {"sw1.fc1", 128, 56, 56, 96, 384, 1, 1, 0},   {"sw1.fc2", 128, 56, 56, 384, 96, 1, 1, 0},
+      {"sw2.qkv", 128, 28, 28, 192, 576, 1, 1, 0},  {"sw2.proj", 128, 28, 28, 192, 192, 1, 1, 0},
+      {"sw2.fc1", 128, 28, 28, 192, 768, 1, 1, 0},  {"sw2.fc2", 128, 28, 28, 768, 192, 1, 1, 0},
+      {"sw3.qkv", 128, 14, 14, 384, 1152, 1, 1, 0}, {"sw3.proj", 128, 14, 14, 384, 384, 1, 1, 0},
+      {"sw3.fc1", 128, 14, 14, 384, 1536, 1, 1, 0}, {"sw3.fc2", 128, 14, 14, 1536, 384, 1, 1, 0},
+      {"sw4.qkv", 128, 7, 7, 768, 2304, 1, 1, 0},   {"sw4.proj", 128, 7, 7, 768, 768, 1, 1, 0},
+      {"sw4.fc1", 128, 7, 7, 768, 3072, 1, 1, 0},   {"sw4.fc2", 128, 7, 7, 3072, 768, 1, 1, 0},
+      // CRNN / decoder linear layers at 512 rows
+      {"fc1.crnn", 512, 1, 1, 36864, 1024, 1, 1, 0}, {"fc2.crnn", 512, 1, 1, 1024, 768, 1, 1, 0},
+      {"lstm.ih", 512, 1, 1, 512, 2048, 1, 1, 0},
   };
   std::vector<Layer> sel;
   for (auto& l : all) {
-    if (argc < 2) { if (l.name[0] == 'l') sel.push_back(l); continue; }
+    if (argc < 2) { if (l.name[0] == 'l' && l.name[1] != 's') sel.push_back(l); continue; }
     for (int i = 1; i < argc; ++i) if (strstr(l.name, argv[i])) { sel.push_back(l); break; }
   }
   uint16_t* flush; const size_t flush_bytes = 1ull << 30;

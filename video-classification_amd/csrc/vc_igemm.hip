@@ -1778,7 +1778,7 @@ int vc_conv_wgrad(const int* desc, int dtype, const void* x, int ldx, const void
   if (dtype == VC_BF16 && !force_naive) {
     VC_CHECK_SHAPE(g.Ci % 8 == 0 && g.Co % 8 == 0, "vc_conv_wgrad: bf16 path needs Ci %% 8 == 0 and Co %% 8 == 0");
     const bool fast = use_glds() && !use_generic_nt();
-    if (fast && vc_wgrad8_eligible(g, ldy_)) {  // wide layers: 256 x 256 tiles, one workgroup per CU
+    if (fast && vc_wgrad8_eligible(g, ldy_, dbias != nullptr)) {  // wide layers: 256 x 256 tiles, one workgroup per CU
       const size_t nw = (size_t)g.Co * g.K;
       const bool det = vc_deterministic();
       int splits, mps;

@@ -458,7 +458,7 @@ void vc_nt8_launch(const ConvGeom& g, int mode, int epi, hipStream_t stream, con
 // vc_wgrad8_plan chooses the slices of the pixel rows (m_per_split a multiple of 64, or 0: slice s works k-tiles s,
 // s + splits, ... of 64 rows); the slices are added with float
 // atomics into dw, or into copies `split_stride` floats apart when that is not zero.
-bool vc_wgrad8_eligible(const ConvGeom& g, int ldy);
+bool vc_wgrad8_eligible(const ConvGeom& g, int ldy, bool with_bias);
 void vc_wgrad8_plan(const ConvGeom& g, size_t det_capacity, bool det, int* splits, int* m_per_split);
 void vc_wgrad8_launch(const ConvGeom& g, const void* x, const void* dy, int ldy, float* dw, int splits, int m_per_split,
                       size_t split_stride, hipStream_t stream);

@@ -278,9 +278,13 @@ bool wgrad8_has(int tco, int tcol) {  // the instantiated shapes
 
 }  // namespace
 
-bool vc_wgrad8_eligible(const ConvGeom& g, int ldy) {
+bool vc_wgrad8_eligible(const ConvGeom& g, int ldy, bool with_bias) {
   const int policy = wgrad8_policy();
   if (!policy) return false;
+  // Layers with a bias keep the 128-wide kernel, which forms the bias gradient from the dy fragments it has staged;
+  // here it would be a column-sum pass over dy of its own (measured: Swin-RNN step 17.8 -> 25.0 ms, the linear layers'
+  // weight gradients 3.9 -> 11.1 ms per step).  VC_WGRAD8=1 takes them anyway.
+  if (with_bias && policy != 1) return false;
   if (g.Ci % 8 || g.Co % 8 || g.ldi % 8 || ldy % 8) return false;
   if (g.kd > 255 || g.kh > 255 || g.kw > 255) return false;
   const int64_t xbytes = (int64_t)g.N * g.Di * g.Hi * g.Wi * g.ldi * 2, ybytes = (int64_t)g.M * ldy * 2;
