@@ -236,3 +236,44 @@ def test_weight_gradient_on_wide_tiles(cuda, shape, det):
         L.call("vc_conv_wgrad", d, 1, L.ptr(x), 0, L.ptr(dy), 0, L.ptr(dw), L.ptr(None), 0, L.stream())
         torch.cuda.synchronize()
     assert _rel(dw - 1, dwn) < 2e-4
+
+
+def test_wide_kernels_on_a_conv3d_geometry(cuda):
+    """Three filter axes (27 taps, the last Conv3D layer's shape at a small clip): forward and data gradient on the wide
+    tile bit-identical to the 128-wide kernel, weight gradient on the wide tile against the plain-FMA kernel."""
+    from video_classification_amd import _lib as L
+    N, D, H, W, Ci, Co = 2, 4, 14, 12, 128, 256
+    g = torch.Generator().manual_seed(51)
+    M = N * D * H * W
+    x = torch.randn(M, Ci, generator=g).to(cuda, torch.bfloat16)
+    dy = torch.randn(M, Co, generator=g).to(cuda, torch.bfloat16)
+    wf = (torch.randn(Co, 27, Ci, generator=g) * 0.05).to(cuda, torch.bfloat16)
+    wt = wf.permute(2, 1, 0).contiguous()
+    d = L.int_array([N, D, H, W, Ci, D, H, W, Co, 3, 3, 3, 1, 1, 1, 1, 1, 1])
+    res = {}
+    for wide in (0, 1):
+        with _Wide(wide):
+            y = torch.full((M, Co), float("nan"), device=cuda, dtype=torch.bfloat16)
+            dx = torch.full((M, Ci), float("nan"), device=cuda, dtype=torch.bfloat16)
+            L.call("vc_conv_fwd", d, 1, L.ptr(x), 0, L.ptr(wf), L.ptr(None), L.ptr(y), 0, 0, 0, 0, L.stream())
+            L.call("vc_conv_dgrad", d, 1, L.ptr(dy), 0, L.ptr(wt), L.ptr(dx), 0, 0, 0, L.stream())
+            torch.cuda.synchronize()
+            res[wide] = (y, dx)
+    assert not torch.isnan(res[1][0].float()).any() and not torch.isnan(res[1][1].float()).any()
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    yn = torch.empty(M, Co, device=cuda, dtype=torch.float32)
+    L.call("vc_conv_fwd_naive_bf16", d, 0, L.ptr(x), L.ptr(wf), L.ptr(None), L.ptr(yn), 0, 1, L.stream())
+    dwn = torch.zeros(Co, 27, Ci, device=cuda)
+    L.call("vc_conv_wgrad", d, 1, L.ptr(x), 0, L.ptr(dy), 0, L.ptr(dwn), L.ptr(None), 1, L.stream())
+    torch.cuda.synchronize()
+    assert _rel(res[1][0].float(), yn) < 8e-3
+    for il in ("1", "0"):  # interleaved and contiguous row slices
+        os.environ["VC_WGRAD8_IL"] = il
+        try:
+            with _WideW(1):
+                dw = torch.zeros(Co, 27, Ci, device=cuda)
+                L.call("vc_conv_wgrad", d, 1, L.ptr(x), 0, L.ptr(dy), 0, L.ptr(dw), L.ptr(None), 0, L.stream())
+                torch.cuda.synchronize()
+        finally:
+            del os.environ["VC_WGRAD8_IL"]
+        assert _rel(dw, dwn) < 2e-4, il
