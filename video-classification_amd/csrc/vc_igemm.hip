@@ -394,7 +394,11 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
       for (int i = 0; i < 4; ++i) {
         const int pix = gather_pixel<MODE>(g, rp[i], c.rd, c.rh, c.rw);
         const bool ok = pix >= 0;
+#ifdef VC_ABL_HOTA  // ablation build: source rows from a 64 KiB window (time only)
+        ap[i] = ok ? src + (((size_t)pix * g.ldi) & 0x7FFF) + lchunk * 8 + koff : zero;
+#else
         ap[i] = ok ? src + (size_t)pix * g.ldi + lchunk * 8 + koff : zero;
+#endif
         ainc[i] = ok ? BK : 0;
       }
     }

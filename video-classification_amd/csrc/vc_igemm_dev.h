@@ -1,6 +1,8 @@
 // Device-side helpers shared by the implicit-GEMM translation units (vc_igemm.hip, vc_igemm8.hip): pixel-row decode,
 // gather addressing, LDS-DMA primitives and the epilogues of the NT (forward / data-gradient) kernels.
 #pragma once
+#include <type_traits>
+
 #include "vc_common.h"
 
 namespace {
@@ -240,7 +242,11 @@ __device__ __forceinline__ float gelu_grad_dev(float x) { return vc_gelu_grad(x)
 // clips 53.64 -> 52.75 ms, with 8 clips 17.93 -> 17.85 ms; non-temporal loads of the epilogues' side tensors on top:
 // +0.1 ms on the ResNet step)
 __device__ __forceinline__ void epi_store8(bf16* p, const bf16x8& v) {
+#ifdef VC_ABL_NOSTORE  // ablation build: the tile is not written (time only)
+  if (reinterpret_cast<uintptr_t>(p) == 1) __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(p));
+#else
   __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(p));
+#endif
 }
 
 template <int MODE, int WI, int EPI = EPI_NONE, bool HAS_BIAS = true>
@@ -286,159 +292,171 @@ __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[
   // ResNet-50 step over all layers) and are still cheaper than a pass over y.  Two cheaper-looking forms measured
   // SLOWER: channel pairs on packed fp32 instructions (that layer 0.379 ms, step +1.1 ms), and a fold in which the
   // lanes exchange halves (14 exchanges instead of 48; 48 bytes of scratch at the 256-register limit, step +3.6 ms).
-  float ps[8], pq[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) ps[e] = pq[e] = 0.f;
-  constexpr int NIT = 64 / RPI;
-  const bool vec = co + 7 < g.Co && (g.ldc & 7) == 0;
-  // beta: fetch everything the tile accumulates into up front (one memory latency, not one per row group)
-  bf16x8 oldv[NIT];
-  bf16* orow[NIT];
-  constexpr bool TAIL = EPI == EPI_BN_TAIL;
-  constexpr bool PRE = EPI == EPI_BN_PRE;
-  constexpr bool SIDE_IN = EPI != EPI_NONE && EPI != EPI_GELU_DUAL;  // tail_y is read
-  float psc[PRE ? 8 : 1], psh[PRE ? 8 : 1];
-  if (PRE) {  // host guarantees vec, beta == 0 and 64-row slabs inside one group
-    const int rpg = relu, G = g.M / rpg;
-    const int ms = m0 + wm * 64;
-    const int gi = ms < g.M ? ms / rpg : 0;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      psc[e] = co + e < g.Co ? bias[(size_t)(2 * G + gi) * g.Co + co + e] : 0.f;
-      psh[e] = co + e < g.Co ? bias[(size_t)(3 * G + gi) * g.Co + co + e] : 0.f;
-    }
-  }
-  bf16x8 tyv[SIDE_IN ? NIT : 1];
-  unsigned tbits[TAIL ? NIT : 1];
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int m = m0 + wm * 64 + it * RPI + rr;
-    const bool live = m < g.M && co < g.Co;
-    orow[it] = live ? out + (size_t)(MODE == 2 ? phase_out_pixel(g, m) : m) * g.ldc + co : nullptr;
-    oldv[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    if (beta && live && vec) oldv[it] = *reinterpret_cast<const bf16x8*>(orow[it]);
-    if (SIDE_IN) {
-      tyv[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-      if (live) tyv[it] = *reinterpret_cast<const bf16x8*>(tail_y + (size_t)m * g.Co + co);
-    }
-    if (TAIL) {
-      tbits[it] = 0;
-      if (live) tbits[it] = tail_bits[((size_t)m * g.Co + co) >> 3];
-    }
-  }
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int row = it * RPI + rr;
-    const int m = m0 + wm * 64 + row;
-    bf16x8 v = *reinterpret_cast<const bf16x8*>(stage_buf + row * WC + ((ch ^ (row & (NCH - 1))) << 3));
-    if (!TAIL && !PRE && bn_partial && m < g.M) {
-#pragma unroll
+  // The rest runs in two copies: one for tiles that lie wholly inside the matrix with 16-byte-aligned rows (no per-row
+  // or per-channel predicates: the tests and the branches around every store are a third of the epilogue's
+  // instructions), one with every test for the edge tiles.
+  auto finish = [&](auto full_tag) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    float ps[8], pq[8];
+  #pragma unroll
+    for (int e = 0; e < 8; ++e) ps[e] = pq[e] = 0.f;
+    constexpr int NIT = 64 / RPI;
+    const bool vec = FULL || (co + 7 < g.Co && (g.ldc & 7) == 0);
+    // beta: fetch everything the tile accumulates into up front (one memory latency, not one per row group)
+    bf16x8 oldv[NIT];
+    bf16* orow[NIT];
+    constexpr bool TAIL = EPI == EPI_BN_TAIL;
+    constexpr bool PRE = EPI == EPI_BN_PRE;
+    constexpr bool SIDE_IN = EPI != EPI_NONE && EPI != EPI_GELU_DUAL;  // tail_y is read
+    float psc[PRE ? 8 : 1], psh[PRE ? 8 : 1];
+    if (PRE) {  // host guarantees vec, beta == 0 and 64-row slabs inside one group
+      const int rpg = relu, G = g.M / rpg;
+      const int ms = m0 + wm * 64;
+      const int gi = FULL || ms < g.M ? ms / rpg : 0;
+  #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float t = (float)v[e];
-        ps[e] += t;
-        pq[e] = fmaf(t, t, pq[e]);
+        psc[e] = FULL || co + e < g.Co ? bias[(size_t)(2 * G + gi) * g.Co + co + e] : 0.f;
+        psh[e] = FULL || co + e < g.Co ? bias[(size_t)(3 * G + gi) * g.Co + co + e] : 0.f;
       }
     }
-    bf16* op = orow[it];
-    if (TAIL) {  // host guarantees vec; rows beyond M carry zero bits and contribute nothing
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float t = (float)v[e];
-        if (beta) t += (float)oldv[it][e];
-        v[e] = ((tbits[it] >> e) & 1) ? (bf16)t : (bf16)0.f;
-        const float dz = (float)v[e];
-        ps[e] += dz;
-        pq[e] = fmaf(dz, (float)tyv[it][e], pq[e]);
+    bf16x8 tyv[SIDE_IN ? NIT : 1];
+    unsigned tbits[TAIL ? NIT : 1];
+  #pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int m = m0 + wm * 64 + it * RPI + rr;
+      const bool live = FULL || (m < g.M && co < g.Co);
+      orow[it] = live ? out + (size_t)(MODE == 2 ? phase_out_pixel(g, m) : m) * g.ldc + co : nullptr;
+      oldv[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (beta && live && vec) oldv[it] = *reinterpret_cast<const bf16x8*>(orow[it]);
+      if (SIDE_IN) {
+        tyv[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (live) tyv[it] = *reinterpret_cast<const bf16x8*>(tail_y + (size_t)m * g.Co + co);
       }
-      if (op) epi_store8(op, v);
-    } else if (PRE) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float yy = (float)tyv[it][e];
-        v[e] = fmaf(yy, psc[e], psh[e]) > 0.f ? v[e] : (bf16)0.f;
-        const float dz = (float)v[e];  // rows beyond M: y was read as zero and dz counts for nothing (not stored)
-        if (m < g.M) {
-          ps[e] += dz;
-          pq[e] = fmaf(dz, yy, pq[e]);
+      if (TAIL) {
+        tbits[it] = 0;
+        if (live) tbits[it] = tail_bits[((size_t)m * g.Co + co) >> 3];
+      }
+    }
+  #pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = it * RPI + rr;
+      const int m = m0 + wm * 64 + row;
+      bf16x8 v = *reinterpret_cast<const bf16x8*>(stage_buf + row * WC + ((ch ^ (row & (NCH - 1))) << 3));
+      if (!TAIL && !PRE && bn_partial && (FULL || m < g.M)) {
+  #pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float t = (float)v[e];
+          ps[e] += t;
+          pq[e] = fmaf(t, t, pq[e]);
         }
       }
-      if (op) epi_store8(op, v);
-    } else if (EPI == EPI_GELU_DUAL) {  // host guarantees vec and beta == 0
-      if (op) {
-        bf16x8 gv;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) gv[e] = (bf16)gelu_dev((float)v[e]);
-        epi_store8(op, v);
-        epi_store8(const_cast<bf16*>(tail_y) + (size_t)m * g.Co + co, gv);
-      }
-    } else if (EPI == EPI_RESIDUAL || EPI == EPI_GELU_BWD) {  // host guarantees vec
-      if (op) {
-        // EPI_RESIDUAL with a row scale (stochastic depth): tail_bits carries fp32 scales, one per `relu` rows;
-        // without one, relu < 0 asks for a ReLU AFTER the residual has been added
-        float rs = 1.f;
-        if (EPI == EPI_RESIDUAL && tail_bits) rs = reinterpret_cast<const float*>(tail_bits)[m / relu];
-        const bool relu_sum = EPI == EPI_RESIDUAL && relu < 0;
-#pragma unroll
+      bf16* op = orow[it];
+      if (TAIL) {  // host guarantees vec; rows beyond M carry zero bits and contribute nothing
+  #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float t = (float)v[e];
           if (beta) t += (float)oldv[it][e];
-          if (EPI == EPI_RESIDUAL) {
-            t = fmaf(t, rs, (float)tyv[it][e]);
-            if (relu_sum) t = fmaxf(t, 0.f);
-          } else {
-            t *= gelu_grad_dev((float)tyv[it][e]);
-          }
-          v[e] = (bf16)t;
+          v[e] = ((tbits[it] >> e) & 1) ? (bf16)t : (bf16)0.f;
+          const float dz = (float)v[e];
+          ps[e] += dz;
+          pq[e] = fmaf(dz, (float)tyv[it][e], pq[e]);
         }
-        epi_store8(op, v);
-      }
-    } else if (op) {
-      if (vec) {
-        if (beta) {
-#pragma unroll
+        if (FULL || op) epi_store8(op, v);
+      } else if (PRE) {
+  #pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float yy = (float)tyv[it][e];
+          v[e] = fmaf(yy, psc[e], psh[e]) > 0.f ? v[e] : (bf16)0.f;
+          const float dz = (float)v[e];  // rows beyond M: y was read as zero and dz counts for nothing (not stored)
+          if (FULL || m < g.M) {
+            ps[e] += dz;
+            pq[e] = fmaf(dz, yy, pq[e]);
+          }
+        }
+        if (FULL || op) epi_store8(op, v);
+      } else if (EPI == EPI_GELU_DUAL) {  // host guarantees vec and beta == 0
+        if (FULL || op) {
+          bf16x8 gv;
+  #pragma unroll
+          for (int e = 0; e < 8; ++e) gv[e] = (bf16)gelu_dev((float)v[e]);
+          epi_store8(op, v);
+          epi_store8(const_cast<bf16*>(tail_y) + (size_t)m * g.Co + co, gv);
+        }
+      } else if (EPI == EPI_RESIDUAL || EPI == EPI_GELU_BWD) {  // host guarantees vec
+        if (FULL || op) {
+          // EPI_RESIDUAL with a row scale (stochastic depth): tail_bits carries fp32 scales, one per `relu` rows;
+          // without one, relu < 0 asks for a ReLU AFTER the residual has been added
+          float rs = 1.f;
+          if (EPI == EPI_RESIDUAL && tail_bits) rs = reinterpret_cast<const float*>(tail_bits)[m / relu];
+          const bool relu_sum = EPI == EPI_RESIDUAL && relu < 0;
+  #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            float t = (float)v[e] + (float)oldv[it][e];
-            if (relu) t = fmaxf(t, 0.f);
+            float t = (float)v[e];
+            if (beta) t += (float)oldv[it][e];
+            if (EPI == EPI_RESIDUAL) {
+              t = fmaf(t, rs, (float)tyv[it][e]);
+              if (relu_sum) t = fmaxf(t, 0.f);
+            } else {
+              t *= gelu_grad_dev((float)tyv[it][e]);
+            }
             v[e] = (bf16)t;
           }
+          epi_store8(op, v);
         }
-        epi_store8(op, v);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (co + e < g.Co) {
-            float t = (float)v[e];
-            if (beta) {
-              t += (float)op[e];
+      } else if (FULL || op) {
+        if (vec) {
+          if (beta) {
+  #pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              float t = (float)v[e] + (float)oldv[it][e];
               if (relu) t = fmaxf(t, 0.f);
+              v[e] = (bf16)t;
             }
-            op[e] = (bf16)t;
+          }
+          epi_store8(op, v);
+        } else {
+  #pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (co + e < g.Co) {
+              float t = (float)v[e];
+              if (beta) {
+                t += (float)op[e];
+                if (relu) t = fmaxf(t, 0.f);
+              }
+              op[e] = (bf16)t;
+            }
+        }
+      }
+    }
+    if (bn_partial) {
+      // fold the lanes that hold the same channels (they differ in rr) and let rr == 0 write the slab's row:
+      // bn_partial[slab][0][co] = sum, [slab][1][co] = sum of squares over the slab's 64 pixel rows
+  #pragma unroll
+      for (int e = 0; e < 8; ++e) {
+  #pragma unroll
+        for (int o = NCH; o < 64; o <<= 1) {
+          ps[e] += __shfl_xor(ps[e], o, 64);
+          pq[e] += __shfl_xor(pq[e], o, 64);
+        }
+      }
+      if (rr == 0 && (FULL || (co < g.Co && m0 + wm * 64 < g.M))) {
+        const int slab = (m0 + wm * 64) >> 6;
+        float* d = bn_partial + (size_t)slab * 2 * g.Co + co;
+  #pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (FULL || co + e < g.Co) {
+            d[e] = ps[e];
+            d[g.Co + e] = pq[e];
           }
       }
     }
-  }
-  if (bn_partial) {
-    // fold the lanes that hold the same channels (they differ in rr) and let rr == 0 write the slab's row:
-    // bn_partial[slab][0][co] = sum, [slab][1][co] = sum of squares over the slab's 64 pixel rows
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-#pragma unroll
-      for (int o = NCH; o < 64; o <<= 1) {
-        ps[e] += __shfl_xor(ps[e], o, 64);
-        pq[e] += __shfl_xor(pq[e], o, 64);
-      }
-    }
-    if (rr == 0 && co < g.Co && m0 + wm * 64 < g.M) {
-      const int slab = (m0 + wm * 64) >> 6;
-      float* d = bn_partial + (size_t)slab * 2 * g.Co + co;
-#pragma unroll
-      for (int e = 0; e < 8; ++e)
-        if (co + e < g.Co) {
-          d[e] = ps[e];
-          d[g.Co + e] = pq[e];
-        }
-    }
-  }
+  };
+  const bool full_tile = MODE != 2 && m0 + wm * 64 + 64 <= g.M && n0 + wn * WC + WC <= g.Co && (g.ldc & 7) == 0 &&
+                         (g.Co & 7) == 0;
+  // (64-channel wave tiles only: with the second copy the 64-wide kernel needs 176 registers instead of 168 and loses
+  // its third workgroup per CU)
+  if (WI == 4 && full_tile) finish(std::true_type{});
+  else finish(std::false_type{});
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global access
