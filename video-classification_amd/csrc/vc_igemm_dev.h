@@ -428,7 +428,30 @@ __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[
         }
       }
     }
-    if (bn_partial) {
+    if (bn_partial && WI == 4) {
+      // The lanes that hold the same channels differ in rr (8 row groups).  Their partial sums go through the wave's
+      // image (free by now, 8 row groups x 64 channels x {sum, sum of squares} = 4 KiB): one LDS round trip and 14
+      // additions instead of three dependent cross-lane exchanges of 16 values, and lane l ends up with channel l, so
+      // the slab's row bn_partial[slab][0 / 1][64 channels] is written by two whole-wave stores.
+      float* fs = reinterpret_cast<float*>(stage_buf);
+      f32x4* w = reinterpret_cast<f32x4*>(fs + rr * 64 + ch * 8);
+      w[0] = f32x4{ps[0], ps[1], ps[2], ps[3]};
+      w[1] = f32x4{ps[4], ps[5], ps[6], ps[7]};
+      w[128] = f32x4{pq[0], pq[1], pq[2], pq[3]};  // + 512 floats
+      w[129] = f32x4{pq[4], pq[5], pq[6], pq[7]};
+      float s = 0.f, q = 0.f;
+  #pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        s += fs[r * 64 + lane];
+        q += fs[512 + r * 64 + lane];
+      }
+      const int cl = n0 + wn * WC + lane;
+      if (FULL || (cl < g.Co && m0 + wm * 64 < g.M)) {
+        float* d = bn_partial + (size_t)((m0 + wm * 64) >> 6) * 2 * g.Co + cl;
+        d[0] = s;
+        d[g.Co] = q;
+      }
+    } else if (bn_partial) {
       // fold the lanes that hold the same channels (they differ in rr) and let rr == 0 write the slab's row:
       // bn_partial[slab][0][co] = sum, [slab][1][co] = sum of squares over the slab's 64 pixel rows
   #pragma unroll
