@@ -428,11 +428,12 @@ __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[
         }
       }
     }
-    if (bn_partial && WI == 4) {
+    if (bn_partial && WI == 4 && !TAIL) {
       // The lanes that hold the same channels differ in rr (8 row groups).  Their partial sums go through the wave's
       // image (free by now, 8 row groups x 64 channels x {sum, sum of squares} = 4 KiB): one LDS round trip and 14
       // additions instead of three dependent cross-lane exchanges of 16 values, and lane l ends up with channel l, so
-      // the slab's row bn_partial[slab][0 / 1][64 channels] is written by two whole-wave stores.
+      // the slab's row bn_partial[slab][0 / 1][64 channels] is written by two whole-wave stores.  (Not for the
+      // batch-norm backward tail: at its 256 registers this form costs 88 bytes of scratch per lane.)
       float* fs = reinterpret_cast<float*>(stage_buf);
       f32x4* w = reinterpret_cast<f32x4*>(fs + rr * 64 + ch * 8);
       w[0] = f32x4{ps[0], ps[1], ps[2], ps[3]};
@@ -477,8 +478,8 @@ __device__ __forceinline__ void nt_epilogue_lds(const ConvGeom& g, f32x4 (&acc)[
   const bool full_tile = MODE != 2 && m0 + wm * 64 + 64 <= g.M && n0 + wn * WC + WC <= g.Co && (g.ldc & 7) == 0 &&
                          (g.Co & 7) == 0;
   // (64-channel wave tiles only: with the second copy the 64-wide kernel needs 176 registers instead of 168 and loses
-  // its third workgroup per CU)
-  if (WI == 4 && full_tile) finish(std::true_type{});
+  // its third workgroup per CU; the batch-norm backward tail keeps one copy as well, two do not fit its 256 registers)
+  if (WI == 4 && EPI != EPI_BN_TAIL && full_tile) finish(std::true_type{});
   else finish(std::false_type{});
 }
 
