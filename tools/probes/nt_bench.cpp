@@ -60,7 +60,7 @@ __global__ void diff_f32(const float* a, const float* b, size_t n, float* out) {
   atomicMax(reinterpret_cast<int*>(out) + 1, __float_as_int(ma));
 }
 
-struct Layer { const char* name; int N, H, W, Ci, Co, k, s, p; };
+struct Layer { const char* name; int N, H, W, Ci, Co, k, s, p; int kw = 0; };  // kw = 1: taps along H only
 
 int main(int argc, char** argv) {
   const int F = getenv("NTB_FRAMES") ? atoi(getenv("NTB_FRAMES")) : 512;
@@ -91,6 +91,8 @@ int main(int argc, char** argv) {
       // CRNN / decoder linear layers at 512 rows
       {"fc1.crnn", 512, 1, 1, 36864, 1024, 1, 1, 0}, {"fc2.crnn", 512, 1, 1, 1024, 768, 1, 1, 0},
       {"lstm.ih", 512, 1, 1, 512, 2048, 1, 1, 0},
+      // ResNet stem over row triples: 3 taps along H of 64 channels (3 rows x 7 taps x 3 colours)
+      {"stem.rows", F, 112, 112, 64, 64, 3, 1, 1, 1},
   };
   std::vector<Layer> sel;
   for (auto& l : all) {
@@ -103,8 +105,9 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1; HIP(hipEventCreate(&e0)); HIP(hipEventCreate(&e1));
   printf("%-10s %-28s %8s | %-7s %8s %8s | %8s %8s | %9s %9s\n", "layer", "N,H,W,Ci->Co k s", "GF", "pass", "nt8 ms", "nt8 TF", "old ms", "old TF", "d(new,old)", "d(naive)");
   for (auto& l : sel) {
-    const int Ho = (l.H + 2 * l.p - l.k) / l.s + 1, Wo = (l.W + 2 * l.p - l.k) / l.s + 1, taps = l.k * l.k;
-    const int desc[18] = {l.N, 1, l.H, l.W, l.Ci, 1, Ho, Wo, l.Co, 1, l.k, l.k, 1, l.s, l.s, 0, l.p, l.p};
+    const int kw = l.kw ? l.kw : l.k, pw = l.kw ? 0 : l.p, sw = l.kw ? 1 : l.s;
+    const int Ho = (l.H + 2 * l.p - l.k) / l.s + 1, Wo = (l.W + 2 * pw - kw) / sw + 1, taps = l.k * kw;
+    const int desc[18] = {l.N, 1, l.H, l.W, l.Ci, 1, Ho, Wo, l.Co, 1, l.k, kw, 1, l.s, sw, 0, l.p, pw};
     const size_t nx = (size_t)l.N * l.H * l.W * l.Ci, ny = (size_t)l.N * Ho * Wo * l.Co, nw = (size_t)l.Co * taps * l.Ci;
     uint16_t *x, *dy, *wf, *wt, *y0, *y1, *dx0, *dx1; float* yn;
     HIP(hipMalloc(&x, nx * 2)); HIP(hipMalloc(&dy, ny * 2)); HIP(hipMalloc(&wf, nw * 2)); HIP(hipMalloc(&wt, nw * 2));

@@ -352,6 +352,7 @@ __global__ void patch_merge_kernel(const T* __restrict__ in, T* __restrict__ out
 // ============================================================================================
 constexpr int AW = 4;             // waves (units) per block
 constexpr int TS = 64 * HD;       // elements of one [64 tokens][32] bf16 tile
+constexpr int PSTR = 68;          // row stride (elements) of the backward pass's [16 queries][64 keys] transposing buffers
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
 
@@ -376,6 +377,13 @@ __device__ __forceinline__ bf16x8 frag_tr(const bf16* tile, int s, int te, int l
   u.s.a = lo;
   u.s.b = hi;
   return u.v;
+}
+
+// 16-deep operand fragment through the transposing read: from a row-major tile (row stride `stride` elements) whose
+// rows are the contraction index, lane gets column 16*tc + (lane & 15) at rows 4*(lane >> 4) .. + 3
+__device__ __forceinline__ s16x4 frag_tr16(const bf16* tile, int stride, int tc, int lane) {
+  const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(tile + (4 * g + q) * stride + 16 * tc + 4 * pp));
 }
 
 // B fragment for k-step s from accumulator tiles t[2s], t[2s+1] (4 values each)
@@ -574,11 +582,13 @@ __global__ __launch_bounds__(64 * AW, 1) __attribute__((amdgpu_waves_per_eu(1, 1
   __shared__ __attribute__((aligned(1024))) bf16 sT2[AW][2][4][TS];
   __shared__ float sBias[AW][176];
   __shared__ float sBin[176];
-  __shared__ f32x4 sBT2[16][64];   // bias (+ -inf of the padded keys) of the elements a lane owns in orientation 2
+  // P and dS of one query tile (16 queries x 64 keys, bf16, rows padded to 136 bytes against bank conflicts), written
+  // in the first orientation's register layout and read back TRANSPOSED as MFMA operands of the products that contract
+  // over the queries
+  __shared__ __attribute__((aligned(16))) bf16 sPS[AW][2][16 * PSTR];
   __shared__ int sReg2[AW][2][64];
   __shared__ int sTok2[AW][2][64];
   __shared__ int sRC[64];
-  __shared__ float sMax[AW][64], sInv[AW][64], sDot[AW][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int gq = lane >> 4, l15 = lane & 15;
   const int N = g.ws * g.ws;
@@ -590,25 +600,22 @@ __global__ __launch_bounds__(64 * AW, 1) __attribute__((amdgpu_waves_per_eu(1, 1
   for (int k = lane; k < nb; k += 64) sBias[wave][k] = bias_table[k * g.heads + head];
   __syncthreads();
 
-  // orientation 1: element (ti, tj, r) = (query i = 16ti + l15, key j = 16tj + 4gq + r)
-  // orientation 2: element (ti, r, tj) = (query i = 16ti + 4gq + r, key j = 16tj + l15)
-  float bt1[4][4][4], dbacc[4][4][4];
+  // a lane's element (ti, tj, r) = (query i = 16ti + l15, key j = 16tj + 4gq + r).  The bias enters as the C operand
+  // of the product that forms the scores, divided by the scale that multiplies the sum afterwards: as an accumulator
+  // input it needs no register move and no addition.  The scores are kept in units of log2(e), so that the
+  // exponential is the bare v_exp_f32.
+  f32x4 bt1[4][4];
+  float dbacc[4][4][4];
+  const float scale2 = scale * 1.4426950408889634f, rscale = 1.f / scale;
 #pragma unroll
   for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
     for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        {
-          const int i = 16 * ti + l15, j = 16 * tj + 4 * gq + r;
-          const int ic = i < N ? i : N - 1;
-          bt1[ti][tj][r] = j < N ? sBias[wave][sRC[ic] - sRC[j] + off] : -INFINITY;
-        }
-        if (ti == wave) {  // the second orientation's table is the same for every wave: one copy in LDS, a row tile each
-          const int i = 16 * ti + 4 * gq + r, j = 16 * tj + l15;
-          const int ic = i < N ? i : N - 1;
-          sBT2[ti * 4 + r][lane][tj] = j < N ? sBias[wave][sRC[ic] - sRC[j] + off] : -INFINITY;
-        }
+        const int i = 16 * ti + l15, j = 16 * tj + 4 * gq + r;
+        const int ic = i < N ? i : N - 1;
+        bt1[ti][tj][r] = j < N ? sBias[wave][sRC[ic] - sRC[j] + off] * rscale : -INFINITY;
         dbacc[ti][tj][r] = 0.f;
       }
   __syncthreads();
@@ -673,30 +680,28 @@ __global__ __launch_bounds__(64 * AW, 1) __attribute__((amdgpu_waves_per_eu(1, 1
     const bf16* tV = sT2[wave][cur][2];
     const bf16* tD = sT2[wave][cur][3];
     // shift-mask regions of this window for the elements the lane owns (padded tokens take token N-1's)
-    int ri1[4], rj1[4][4], ri2[4][4], rj2[4];
+    int ri1[4], rj1[4][4];
     if (g.shift) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int i1 = 16 * t + l15;
         ri1[t] = sRegW[i1 < N ? i1 : N - 1];
-        const int j2 = 16 * t + l15;
-        rj2[t] = sRegW[j2 < N ? j2 : N - 1];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int x = 16 * t + 4 * gq + r;
-          const int v = sRegW[x < N ? x : N - 1];
-          rj1[t][r] = v;
-          ri2[t][r] = v;
+          rj1[t][r] = sRegW[x < N ? x : N - 1];
         }
       }
     }
 
-    // ---- orientation 1: rows j, columns i (lane <-> query i); one column tile ti at a time ------------
-    f32x4 dq[2][4];
+    // ---- rows j, columns i (lane <-> query i); one column tile ti (16 queries) at a time ------------
+    f32x4 dq[2][4], dv[2][4], dk[2][4];
 #pragma unroll
     for (int te = 0; te < 2; ++te)
 #pragma unroll
-      for (int ti = 0; ti < 4; ++ti) dq[te][ti] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < 4; ++t) dq[te][t] = dv[te][t] = dk[te][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16* bufP = sPS[wave][0];
+    bf16* bufS = sPS[wave][1];
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti) {
       const int i = 16 * ti + l15;
@@ -704,7 +709,7 @@ __global__ __launch_bounds__(64 * AW, 1) __attribute__((amdgpu_waves_per_eu(1, 1
       f32x4 st[4], dp[4];
 #pragma unroll
       for (int tj = 0; tj < 4; ++tj) {
-        st[tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(tK, tj, lane), qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        st[tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(tK, tj, lane), qf, bt1[ti][tj], 0, 0, 0);
         dp[tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(tV, tj, lane), df, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
       }
       float mx = -INFINITY;
@@ -712,8 +717,8 @@ __global__ __launch_bounds__(64 * AW, 1) __attribute__((amdgpu_waves_per_eu(1, 1
       for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float sc = fmaf(st[tj][r], scale, bt1[ti][tj][r]);
-          if (g.shift && ri1[ti] != rj1[tj][r]) sc -= 100.f;
+          float sc = st[tj][r] * scale2;
+          if (g.shift && ri1[ti] != rj1[tj][r]) sc -= 100.f * 1.4426950408889634f;
           st[tj][r] = sc;
           mx = fmaxf(mx, sc);
         }
@@ -724,7 +729,7 @@ __global__ __launch_bounds__(64 * AW, 1) __attribute__((amdgpu_waves_per_eu(1, 1
       for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = __expf(st[tj][r] - mx);
+          const float e = __builtin_amdgcn_exp2f(st[tj][r] - mx);
           st[tj][r] = e;
           sum += e;
         }
@@ -741,12 +746,15 @@ __global__ __launch_bounds__(64 * AW, 1) __attribute__((amdgpu_waves_per_eu(1, 1
         }
       dot += __shfl_xor(dot, 16, 64);
       dot += __shfl_xor(dot, 32, 64);
-      if (gq == 0) {
-        sMax[wave][i] = mx;
-        sInv[wave][i] = inv;
-        sDot[wave][i] = dot;
-      }
       const float live = ((i < N) && uvalid) ? 1.f : 0.f;  // padded queries / windows add nothing to the bias
+      // P^T of this query tile goes to LDS as it stands (row = the lane's query, 4 consecutive keys per store) ...
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj) {
+        bf16x4 pb;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pb[r] = (bf16)st[tj][r];
+        *reinterpret_cast<bf16x4*>(bufP + l15 * PSTR + 16 * tj + 4 * gq) = pb;
+      }
 #pragma unroll
       for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
@@ -755,13 +763,37 @@ __global__ __launch_bounds__(64 * AW, 1) __attribute__((amdgpu_waves_per_eu(1, 1
           st[tj][r] = ds;
           dbacc[ti][tj][r] = fmaf(live, ds, dbacc[ti][tj][r]);
         }
-      // dQ^T[e][i] += sum_j K^T[e][j] dS^T[j][i]
+      // dQ^T[e][i] += sum_j K^T[e][j] dS^T[j][i]; ... and so does dS^T, in the bf16 rounding the product above uses
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const bf16x8 sf = frag_from_acc(st[2 * s2], st[2 * s2 + 1]);
+        *reinterpret_cast<bf16x4*>(bufS + l15 * PSTR + 16 * (2 * s2) + 4 * gq) = bf16x4{sf[0], sf[1], sf[2], sf[3]};
+        *reinterpret_cast<bf16x4*>(bufS + l15 * PSTR + 16 * (2 * s2 + 1) + 4 * gq) = bf16x4{sf[4], sf[5], sf[6], sf[7]};
 #pragma unroll
         for (int te = 0; te < 2; ++te)
           dq[te][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(tK, s2, te, lane), sf, dq[te][ti], 0, 0, 0);
+      }
+      // The products that contract over the queries take P and dS of these 16 queries as B operands (k = query,
+      // n = key), read back through the transposing LDS read; their A operands are dO^T and Q^T of the same 16 tokens:
+      //   dV^T[e][j] += sum_i dO^T[e][i] P[i][j];   dK^T[e][j] += sum_i Q^T[e][i] dS[i][j]
+      // Padded queries (i >= N) have zero rows in Q and dO and a finite P: they add nothing.
+      wave_lds_fence();
+      {
+        s16x4 dt[2], qt[2];
+#pragma unroll
+        for (int te = 0; te < 2; ++te) {
+          dt[te] = frag_tr16(tD + 16 * ti * HD, HD, te, lane);
+          qt[te] = frag_tr16(tQ + 16 * ti * HD, HD, te, lane);
+        }
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) {
+          const s16x4 pf = frag_tr16(bufP, PSTR, tj, lane), sfj = frag_tr16(bufS, PSTR, tj, lane);
+#pragma unroll
+          for (int te = 0; te < 2; ++te) {
+            dv[te][tj] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dt[te], pf, dv[te][tj], 0, 0, 0);
+            dk[te][tj] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qt[te], sfj, dk[te][tj], 0, 0, 0);
+          }
+        }
       }
     }
     if (uvalid) {
@@ -776,52 +808,6 @@ __global__ __launch_bounds__(64 * AW, 1) __attribute__((amdgpu_waves_per_eu(1, 1
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = (bf16)(dq[te][ti][r] * scale);
           *reinterpret_cast<bf16x4*>(drow + 16 * te + 4 * gq) = v;
-        }
-      }
-    }
-    wave_lds_fence();  // sMax / sInv / sDot written by the lanes that own i are read by every lane of the wave
-    // ---- orientation 2: rows i, columns j (lane <-> key j); two row tiles (one k-step) at a time ---------
-    f32x4 dv[2][4], dk[2][4];
-#pragma unroll
-    for (int te = 0; te < 2; ++te)
-#pragma unroll
-      for (int tj = 0; tj < 4; ++tj) dv[te][tj] = dk[te][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      f32x4 st[2][4], dp[2][4];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int ti = 2 * s2 + h;
-        const bf16x8 qf = frag_rows(tQ, ti, lane), df = frag_rows(tD, ti, lane);
-#pragma unroll
-        for (int tj = 0; tj < 4; ++tj) {
-          st[h][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, frag_rows(tK, tj, lane), f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-          dp[h][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, frag_rows(tV, tj, lane), f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = 16 * ti + 4 * gq + r;
-          const float mx = sMax[wave][i], dot = sDot[wave][i];
-          const float inv = (i < N) ? sInv[wave][i] : 0.f;  // padded queries contribute nothing
-          const f32x4 b2 = sBT2[ti * 4 + r][lane];
-#pragma unroll
-          for (int tj = 0; tj < 4; ++tj) {
-            float sc = fmaf(st[h][tj][r], scale, b2[tj]);
-            if (g.shift && ri2[ti][r] != rj2[tj]) sc -= 100.f;
-            const float p = __expf(sc - mx) * inv;  // P[i][j]
-            st[h][tj][r] = p;
-            dp[h][tj][r] = p * (dp[h][tj][r] - dot);                // dS[i][j]
-          }
-        }
-      }
-      // dV^T[e][j] += sum_i dO^T[e][i] P[i][j];  dK^T[e][j] += sum_i Q^T[e][i] dS[i][j]
-#pragma unroll
-      for (int te = 0; te < 2; ++te) {
-        const bf16x8 dt = frag_tr(tD, s2, te, lane), qt = frag_tr(tQ, s2, te, lane);
-#pragma unroll
-        for (int tj = 0; tj < 4; ++tj) {
-          dv[te][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dt, frag_from_acc(st[0][tj], st[1][tj]), dv[te][tj], 0, 0, 0);
-          dk[te][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, frag_from_acc(dp[0][tj], dp[1][tj]), dk[te][tj], 0, 0, 0);
         }
       }
     }
@@ -933,8 +919,11 @@ int vc_window_attn_bwd(int dtype, const void* qkv, const void* dout, const float
   while ((int64_t)ceil_div(windows, wpb) * heads > 8192) wpb *= 2;
   dim3 grid(ceil_div(windows, wpb), heads);
   if (dtype == VC_BF16) {
-    int wpw = 1;  // windows per wave: enough blocks to fill the chip, few enough that the bias atomics stay cheap
-    while ((int64_t)ceil_div(windows, AW * wpw) * heads > 1024) wpw *= 2;
+    // Windows per wave: one block per CU (its LDS holds one) in ONE round, so that what a block does once -- the bias
+    // tables of its head into registers, the fold of the bias gradient at the end -- is paid once per CU and not once
+    // per round (three rounds of 8 windows per wave at 128 frames of stage 1: 309 us; one round of 25: see below).
+    const int chunks = vc_device_cus() / heads > 0 ? vc_device_cus() / heads : 1;
+    const int wpw = ceil_div(windows, AW * chunks);
     dim3 mgrid(ceil_div(windows, AW * wpw), heads);
     // deterministic mode: a copy of the bias-gradient table per block column, added in order afterwards
     const size_t nbins = (size_t)(2 * ws - 1) * (2 * ws - 1) * heads;
