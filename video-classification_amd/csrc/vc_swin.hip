@@ -431,126 +431,6 @@ __device__ __forceinline__ float score_of(float acc, int row, int col, int N, in
   return s;
 }
 
-__global__ __launch_bounds__(64 * AW) void window_attn_fwd_mfma_kernel(SwinGeom g, const bf16* __restrict__ qkv,
-                                                                        const float* __restrict__ bias_table,
-                                                                        bf16* __restrict__ out, float scale,
-                                                                        int units_total) {
-  __shared__ __attribute__((aligned(16))) bf16 sT[AW][3][TS];   // q, k, v tiles per wave
-  __shared__ float sBias[AW][176];
-  __shared__ int sReg[AW][64];
-  __shared__ int sTok[AW][64];
-  __shared__ int sRC[64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int N = g.ws * g.ws;
-  if (threadIdx.x < 64) sRC[threadIdx.x] = (threadIdx.x / g.ws) * (2 * g.ws - 1) + (threadIdx.x % g.ws);
-  int unit = blockIdx.x * AW + wave;
-  const bool uvalid = unit < units_total;
-  if (!uvalid) unit = units_total - 1;
-  const int head = unit % g.heads;
-  int u = unit / g.heads;
-  const int ww = u % g.nww;
-  u /= g.nww;
-  const int wh = u % g.nwh;
-  const int b = u / g.nwh;
-
-  int tok = 0, reg = 0;
-  const bool tvalid = lane < N;
-  if (tvalid) {
-    int ph, pw;
-    tok = token_of(g, b, wh, ww, lane, ph, pw);
-    reg = region_of(ph, g.H, g.ws, g.shift) * 3 + region_of(pw, g.W, g.ws, g.shift);
-  }
-  sReg[wave][lane] = reg;
-  sTok[wave][lane] = tvalid ? tok : -1;
-  const int nb = (2 * g.ws - 1) * (2 * g.ws - 1);
-  for (int k = lane; k < nb; k += 64) sBias[wave][k] = bias_table[k * g.heads + head];
-#pragma unroll
-  for (int w3 = 0; w3 < 3; ++w3) stage_tile(sT[wave][w3], qkv, (size_t)3 * g.C, w3 * g.C + head * HD, tok, tvalid, lane);
-  __syncthreads();
-
-  const bf16* tQ = sT[wave][0];
-  const bf16* tK = sT[wave][1];
-  const bf16* tV = sT[wave][2];
-  bf16x8 qf[4], kf[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    qf[t] = frag_rows(tQ, t, lane);
-    kf[t] = frag_rows(tK, t, lane);
-  }
-  f32x4 st[4][4];  // S^T[tj][ti]
-#pragma unroll
-  for (int tj = 0; tj < 4; ++tj)
-#pragma unroll
-    for (int ti = 0; ti < 4; ++ti)
-      st[tj][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[tj], qf[ti], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-
-  const int gq = lane >> 4;
-  float inv_sum[4];
-#pragma unroll
-  for (int ti = 0; ti < 4; ++ti) {
-    const int i = 16 * ti + (lane & 15);
-    float mx = -INFINITY;
-#pragma unroll
-    for (int tj = 0; tj < 4; ++tj)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float s = score_of<true>(st[tj][ti][r], 16 * tj + 4 * gq + r, i, N, g.ws, sBias[wave], sReg[wave], sRC,
-                                       g.shift, scale);
-        st[tj][ti][r] = s;
-        mx = fmaxf(mx, s);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float sum = 0.f;
-#pragma unroll
-    for (int tj = 0; tj < 4; ++tj)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float e = __expf(st[tj][ti][r] - mx);
-        st[tj][ti][r] = e;
-        sum += e;
-      }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    inv_sum[ti] = 1.f / sum;
-  }
-
-  f32x4 ot[2][4];  // O^T[te][ti]
-#pragma unroll
-  for (int te = 0; te < 2; ++te)
-#pragma unroll
-    for (int ti = 0; ti < 4; ++ti) ot[te][ti] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    bf16x8 vt[2], pf[4];
-#pragma unroll
-    for (int te = 0; te < 2; ++te) vt[te] = frag_tr(tV, s, te, lane);
-#pragma unroll
-    for (int ti = 0; ti < 4; ++ti) pf[ti] = frag_from_acc(st[2 * s][ti], st[2 * s + 1][ti]);
-#pragma unroll
-    for (int te = 0; te < 2; ++te)
-#pragma unroll
-      for (int ti = 0; ti < 4; ++ti)
-        ot[te][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt[te], pf[ti], ot[te][ti], 0, 0, 0);
-  }
-  if (uvalid) {
-#pragma unroll
-    for (int ti = 0; ti < 4; ++ti) {
-      const int i = 16 * ti + (lane & 15);
-      if (i >= N) continue;
-      const int tk = sTok[wave][i];
-      bf16* orow = out + (size_t)tk * g.C + head * HD;
-#pragma unroll
-      for (int te = 0; te < 2; ++te) {
-        bf16x4 v;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = (bf16)(ot[te][ti][r] * inv_sum[ti]);
-        *reinterpret_cast<bf16x4*>(orow + 16 * te + 4 * gq) = v;
-      }
-    }
-  }
-}
-
 __device__ __attribute__((aligned(64))) const uint32_t swin_zero_src[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 typedef __attribute__((address_space(1))) const void* swin_gptr_t;
 typedef __attribute__((address_space(3))) void* swin_lptr_t;
@@ -563,6 +443,165 @@ __device__ __forceinline__ void glds16_swin(const void* gsrc, bf16* lds_wave_bas
 __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// Forward.  grid = (window chunks, heads); each wave walks `wpw` windows of one head, so that what depends on the head
+// only is set up once per wave: the relative-position bias (and the -inf of the padded keys) of the 64 (i, j) elements
+// a lane owns sits in registers and enters as the C operand of the product that forms the scores (divided by the scale
+// that multiplies the sum afterwards), and the scores are kept in units of log2(e) so that the exponential is the bare
+// v_exp_f32.  The q / k / v tiles of a window arrive by LDS-DMA (12 requests per lane, no staging registers); one tile
+// set per wave keeps two blocks on a CU (194 registers per lane), whose other waves cover the wait for the next
+// window's tiles.  One query tile (16 queries) at a time: 16 scores, the softmax of its column, the product with V
+// and the store.
+__global__ __launch_bounds__(64 * AW) void window_attn_fwd_mfma_kernel(SwinGeom g, const bf16* __restrict__ qkv,
+                                                                        const float* __restrict__ bias_table,
+                                                                        bf16* __restrict__ out, float scale,
+                                                                        int windows_total, int wpw) {
+  __shared__ __attribute__((aligned(1024))) bf16 sT[AW][3][TS];  // q, k, v tiles per wave
+  __shared__ float sBias[AW][176];
+  __shared__ int sReg2[AW][2][64];
+  __shared__ int sTok2[AW][2][64];
+  __shared__ int sRC[64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int gq = lane >> 4, l15 = lane & 15;
+  const int N = g.ws * g.ws;
+  const int head = blockIdx.y;
+  const int nb = (2 * g.ws - 1) * (2 * g.ws - 1);
+  const int off = (g.ws - 1) * (2 * g.ws);
+  if (threadIdx.x < 64) sRC[threadIdx.x] = (threadIdx.x / g.ws) * (2 * g.ws - 1) + (threadIdx.x % g.ws);
+  for (int k = lane; k < nb; k += 64) sBias[wave][k] = bias_table[k * g.heads + head];
+  __syncthreads();
+
+  // a lane's element (ti, tj, r) = (query i = 16ti + l15, key j = 16tj + 4gq + r)
+  f32x4 bt[4][4];
+  const float scale2 = scale * 1.4426950408889634f, rscale = 1.f / scale;
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * ti + l15, j = 16 * tj + 4 * gq + r;
+        const int ic = i < N ? i : N - 1;
+        bt[ti][tj][r] = j < N ? sBias[wave][sRC[ic] - sRC[j] + off] * rscale : -INFINITY;
+      }
+
+  const int w_first = (blockIdx.x * AW + wave) * wpw;
+  const bool tvalid = lane < N;
+  // tokens and shift-mask regions of window `it` into table set `buf`; its three operand tiles requested into the
+  // wave's tile set (lane l of request k fetches 16 bytes of token 16k + l/4; rows past the window's end a zero line)
+  auto request_window = [&](int it, int buf) {
+    int win = w_first + it;
+    if (win >= windows_total) win = windows_total - 1;
+    int u = win;
+    const int ww = u % g.nww;
+    u /= g.nww;
+    const int wh = u % g.nwh;
+    const int b = u / g.nwh;
+    int tok = 0, reg = 0;
+    if (tvalid) {
+      int ph, pw;
+      tok = token_of(g, b, wh, ww, lane, ph, pw);
+      reg = region_of(ph, g.H, g.ws, g.shift) * 3 + region_of(pw, g.W, g.ws, g.shift);
+    }
+    sReg2[wave][buf][lane] = reg;
+    sTok2[wave][buf][lane] = tvalid ? tok : -1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int t = 16 * k + (lane >> 2);
+      const int tk = __shfl(tok, t, 64);
+      const bool ok = t < N;
+      const bf16* zero = reinterpret_cast<const bf16*>(swin_zero_src);
+#pragma unroll
+      for (int w3 = 0; w3 < 3; ++w3)
+        glds16_swin(ok ? qkv + (size_t)tk * 3 * g.C + w3 * g.C + head * HD + 8 * (lane & 3) : zero,
+                    sT[wave][w3] + k * 16 * HD);
+    }
+  };
+  const bf16* tQ = sT[wave][0];
+  const bf16* tK = sT[wave][1];
+  const bf16* tV = sT[wave][2];
+  request_window(0, 0);
+  for (int it = 0; it < wpw; ++it) {
+    const int cur = it & 1;
+    const bool uvalid = w_first + it < windows_total;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wave_lds_fence();
+    const int* sRegW = sReg2[wave][cur];
+    const int* sTokW = sTok2[wave][cur];
+    int ri[4], rj[4][4];
+    if (g.shift) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int i1 = 16 * t + l15;
+        ri[t] = sRegW[i1 < N ? i1 : N - 1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int x = 16 * t + 4 * gq + r;
+          rj[t][r] = sRegW[x < N ? x : N - 1];
+        }
+      }
+    }
+    bf16x8 kf[4], vt[2][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) kf[t] = frag_rows(tK, t, lane);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int te = 0; te < 2; ++te) vt[s][te] = frag_tr(tV, s, te, lane);
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {
+      const int i = 16 * ti + l15;
+      const bf16x8 qf = frag_rows(tQ, ti, lane);
+      f32x4 st[4];  // S^T[tj] of this query tile
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj) st[tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[tj], qf, bt[ti][tj], 0, 0, 0);
+      float mx = -INFINITY;
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float sc = st[tj][r] * scale2;
+          if (g.shift && ri[ti] != rj[tj][r]) sc -= 100.f * 1.4426950408889634f;
+          st[tj][r] = sc;
+          mx = fmaxf(mx, sc);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __builtin_amdgcn_exp2f(st[tj][r] - mx);
+          st[tj][r] = e;
+          sum += e;
+        }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv = 1.f / sum;
+      f32x4 ot[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};  // O^T[te] of this query tile
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 pf = frag_from_acc(st[2 * s], st[2 * s + 1]);
+#pragma unroll
+        for (int te = 0; te < 2; ++te) ot[te] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt[s][te], pf, ot[te], 0, 0, 0);
+      }
+      if (uvalid && i < N) {
+        bf16* orow = out + (size_t)sTokW[i] * g.C + head * HD;
+#pragma unroll
+        for (int te = 0; te < 2; ++te) {
+          bf16x4 v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = (bf16)(ot[te][r] * inv);
+          *reinterpret_cast<bf16x4*>(orow + 16 * te + 4 * gq) = v;
+        }
+      }
+    }
+    // the tile set is free once every read of it has been served (the LDS keeps a wave's instructions in order)
+    wave_lds_fence();
+    if (it + 1 < wpw) request_window(it + 1, cur ^ 1);
+  }
 }
 
 // grid = (window chunks, heads); each wave walks `wpw` windows of one head.  Everything that does not depend on
@@ -895,10 +934,14 @@ int vc_window_attn_fwd(int dtype, const void* qkv, const float* bias_table, void
   int rc = fill_swin(g, B, H, W, C, heads, ws, shift, "vc_window_attn_fwd");
   if (rc) return rc;
   const int units = B * g.nwh * g.nww * heads;
-  if (dtype == VC_BF16)
-    hipLaunchKernelGGL(window_attn_fwd_mfma_kernel, dim3(ceil_div(units, AW)), dim3(64 * AW), 0, stream, g,
-                       (const bf16*)qkv, bias_table, (bf16*)out, scale, units);
-  else if (dtype == VC_F32)
+  if (dtype == VC_BF16) {
+    // two blocks per CU (registers and LDS), each wave walking the windows of one head
+    const int windows = B * g.nwh * g.nww;
+    const int chunks = 2 * vc_device_cus() / heads > 0 ? 2 * vc_device_cus() / heads : 1;
+    const int wpw = ceil_div(windows, AW * chunks);
+    hipLaunchKernelGGL(window_attn_fwd_mfma_kernel, dim3(ceil_div(windows, AW * wpw), heads), dim3(64 * AW), 0, stream,
+                       g, (const bf16*)qkv, bias_table, (bf16*)out, scale, windows, wpw);
+  } else if (dtype == VC_F32)
     hipLaunchKernelGGL((window_attn_fwd_kernel<float>), dim3(units), dim3(64), 0, stream, g, (const float*)qkv,
                        bias_table, (float*)out, scale);
   else { vc_set_error("vc_window_attn_fwd: unsupported dtype %d", dtype); return VC_ERR_DTYPE; }
