@@ -193,6 +193,10 @@ WSHAPES = [
     (3, 31, 29, 256, 64, 1, 1),
     (5, 28, 28, 128, 128, 3, 1),
     (7, 28, 27, 128, 512, 1, 1),
+    # linear layers of a Swin block (bias gradient inside the kernel): 96 -> 384, 384 -> 96, 192 -> 768
+    (2, 56, 56, 96, 384, 1, 1),
+    (2, 56, 56, 384, 96, 1, 1),
+    (4, 28, 28, 192, 768, 1, 1),
 ]
 
 
@@ -230,12 +234,17 @@ def test_weight_gradient_on_wide_tiles(cuda, shape, det):
     assert _rel(runs[0][1], dy.float().sum(0)) < 2e-4
     if det:
         assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
-    # accumulation into a non-zero dw
+    # accumulation into a non-zero dw (and bias gradient)
     with _WideW(1):
         dw = torch.ones(Co, k * k, Ci, device=cuda)
         L.call("vc_conv_wgrad", d, 1, L.ptr(x), 0, L.ptr(dy), 0, L.ptr(dw), L.ptr(None), 0, L.stream())
+        dw2 = torch.ones(Co, k * k, Ci, device=cuda)
+        db2 = torch.ones(Co, device=cuda)
+        L.call("vc_conv_wgrad", d, 1, L.ptr(x), 0, L.ptr(dy), 0, L.ptr(dw2), L.ptr(db2), 0, L.stream())
         torch.cuda.synchronize()
     assert _rel(dw - 1, dwn) < 2e-4
+    assert _rel(dw2 - 1, dwn) < 2e-4
+    assert _rel(db2 - 1, dy.float().sum(0)) < 2e-4
 
 
 def test_wide_kernels_on_a_conv3d_geometry(cuda):

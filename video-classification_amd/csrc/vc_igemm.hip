@@ -1793,11 +1793,12 @@ int vc_conv_wgrad(const int* desc, int dtype, const void* x, int ldx, const void
         target = vc_det_workspace((size_t)splits * nw, stream, "vc_conv_wgrad");
         if (!target) return VC_ERR_ARG;
       }
-      vc_wgrad8_launch(g, x, dy, ldy_, target, splits, mps, ordered ? nw : 0, stream);
+      float* const db_fused = det ? nullptr : dbias;  // deterministic mode: an ordered column-sum pass below
+      vc_wgrad8_launch(g, x, dy, ldy_, target, splits, mps, ordered ? nw : 0, db_fused, stream);
       VC_LAUNCH_CHECK("vc_conv_wgrad");
       if (ordered)
         if (int rc2 = vc_det_reduce(dw_packed, target, nw, splits, stream)) return rc2;
-      if (dbias) return vc_colsum(dtype, dy, dbias, g.M, g.Co, ldy_, stream);
+      if (dbias && !db_fused) return vc_colsum(dtype, dy, dbias, g.M, g.Co, ldy_, stream);
       return VC_OK;
     }
     float* dbias_fused = fast ? dbias : nullptr;

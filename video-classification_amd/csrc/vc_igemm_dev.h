@@ -496,11 +496,12 @@ void vc_nt8_launch(const ConvGeom& g, int mode, int epi, hipStream_t stream, con
                    const float* bias, void* out, int relu, int beta, float* bn_partial, const void* tail_y,
                    const uint8_t* tail_bits);
 
-// 256 x 256-tile, 8-wave form of the weight-gradient kernel (vc_wgrad8.hip): bf16, no fused bias gradient.
+// 256 x 256-tile, 8-wave form of the weight-gradient kernel (vc_wgrad8.hip): bf16.
 // vc_wgrad8_plan chooses the slices of the pixel rows (m_per_split a multiple of 64, or 0: slice s works k-tiles s,
 // s + splits, ... of 64 rows); the slices are added with float
-// atomics into dw, or into copies `split_stride` floats apart when that is not zero.
+// atomics into dw, or into copies `split_stride` floats apart when that is not zero.  dbias (or null): the column sums
+// of dy are added to it with float atomics (not with split_stride != 0).
 bool vc_wgrad8_eligible(const ConvGeom& g, int ldy, bool with_bias);
 void vc_wgrad8_plan(const ConvGeom& g, size_t det_capacity, bool det, int* splits, int* m_per_split);
 void vc_wgrad8_launch(const ConvGeom& g, const void* x, const void* dy, int ldy, float* dw, int splits, int m_per_split,
-                      size_t split_stride, hipStream_t stream);
+                      size_t split_stride, float* dbias, hipStream_t stream);

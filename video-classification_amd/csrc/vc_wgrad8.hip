@@ -56,11 +56,12 @@ __device__ __forceinline__ int wswz(int row) {
 }
 
 // Tile = (WN x NI x 16) output channels x (WM x NJ x 16) columns, WN x WM = 8 waves, each NI x NJ accumulator tiles.
-template <int NI, int NJ, int WN, int WM>
+template <int NI, int NJ, int WN, int WM, bool BIAS>
 __global__ __launch_bounds__(NW8, 2) void igemm_tn_wgrad8_kernel(ConvGeom g, const bf16* __restrict__ x,
                                                                  const bf16* __restrict__ dy, int ldy,
                                                                  float* __restrict__ dw, int m_per_split, int ntiles,
-                                                                 int tiles_col, size_t split_stride) {
+                                                                 int tiles_col, size_t split_stride,
+                                                                 float* __restrict__ dbias) {
   static_assert(WN * WM == 8, "eight waves");
   constexpr int TCO = WN * NI * 16, TCOL = WM * NJ * 16;
   static_assert((TCO == 64 || TCO == 128 || TCO == 256) && (TCOL == 64 || TCOL == 128 || TCOL == 256), "tile sides");
@@ -158,6 +159,16 @@ __global__ __launch_bounds__(NW8, 2) void igemm_tn_wgrad8_kernel(ConvGeom g, con
   for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // Bias gradient (BIAS): the column sums of dy are one more product of the dy fragments, with a B operand of ones.  The
+  // workgroups of the first column tile form them; of the WM waves that hold the same dy fragments, wave wm takes the
+  // output-channel tiles i = wm, wm + WM, ...  (every column of such an accumulator tile carries the same sums).
+  constexpr int NB = BIAS ? (NI + WM - 1) / WM : 1;
+  f32x4 bacc[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = BIAS && dbias != nullptr && tile_col == 0;
+  const bf16 one = (bf16)1.0f;
+  const bf16x8 ones = {one, one, one, one, one, one, one, one};
 
   // transposing fragment reads: lane (gq, q, p) reads rows 8 gq + q and + 4 (+ 32 for the second half) of a 16-column
   // block; the block swizzle of those rows is the same.  Address = (base | swizzle bits) ^ (block << 5): the lane part
@@ -226,6 +237,8 @@ __global__ __launch_bounds__(NW8, 2) void igemm_tn_wgrad8_kernel(ConvGeom g, con
     for (int n = 0; n < NM; ++n) {
       const int j = n % NJ, i = n / NJ;
       acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yX[i], xX[j], acc[i][j], 0, 0, 0);
+      if (BIAS && j == 0 && do_bias && i % WM == wm)
+        bacc[BIAS ? i / WM : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yX[i], ones, bacc[BIAS ? i / WM : 0], 0, 0, 0);
       if (n % FSTEP == 0 && n / FSTEP < NF) ldf(yY, xY, st, 1, n / FSTEP);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -237,6 +250,8 @@ __global__ __launch_bounds__(NW8, 2) void igemm_tn_wgrad8_kernel(ConvGeom g, con
     for (int n = 0; n < NM; ++n) {
       const int j = n % NJ, i = n / NJ;
       acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yY[i], xY[j], acc[i][j], 0, 0, 0);
+      if (BIAS && j == 0 && do_bias && i % WM == wm)
+        bacc[BIAS ? i / WM : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yY[i], ones, bacc[BIAS ? i / WM : 0], 0, 0, 0);
       if (n % FSTEP == 0 && n / FSTEP < NF) ldf(yX, xX, stn, 0, n / FSTEP);
       if (n % PSTEP == PSTEP - 1 && n / PSTEP < NP) stage_piece(kt + NS, n / PSTEP);
       __builtin_amdgcn_sched_barrier(0);
@@ -256,6 +271,17 @@ __global__ __launch_bounds__(NW8, 2) void igemm_tn_wgrad8_kernel(ConvGeom g, con
       for (int j = 0; j < NJ; ++j) {
         const int cc = col0 + (wm * NJ + j) * 16 + (lane & 15);
         if (cc < g.K) atomicAdd(dw + (size_t)co * g.K + cc, acc[i][j][r]);
+      }
+    }
+  }
+  if (BIAS && do_bias && (lane & 15) == 0) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      if (i % WM != wm) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + (wn * NI + i) * 16 + (lane >> 4) * 4 + r;
+        if (co < g.Co) atomicAdd(dbias + co, bacc[BIAS ? i / WM : 0][r]);
       }
     }
   }
@@ -281,10 +307,15 @@ bool wgrad8_has(int tco, int tcol) {  // the instantiated shapes
 bool vc_wgrad8_eligible(const ConvGeom& g, int ldy, bool with_bias) {
   const int policy = wgrad8_policy();
   if (!policy) return false;
-  // Layers with a bias keep the 128-wide kernel, which forms the bias gradient from the dy fragments it has staged;
-  // here it would be a column-sum pass over dy of its own (measured: Swin-RNN step 17.8 -> 25.0 ms, the linear layers'
-  // weight gradients 3.9 -> 11.1 ms per step).  VC_WGRAD8=1 takes them anyway.
-  if (with_bias && policy != 1) return false;
+  // Layers with a bias (linear layers: one tap) form the bias gradient inside the kernel as well (not in deterministic
+  // mode: there it is a column-sum pass over dy of its own, and the 128-wide kernel keeps them).  Measured on the Swin-T
+  // layers at 128 frames against the 128-wide kernel: the MLP layers (one side four times the other) gain 8-20 % at
+  // every stage, 96 -> 288 gains 23 %, the other qkv and the square projections lose 5-20 %.
+  if (with_bias && policy != 1) {
+    const int lo = g.Co < g.K ? g.Co : g.K, hi = g.Co < g.K ? g.K : g.Co;
+    if (vc_deterministic() || g.kd * g.kh * g.kw != 1 || g.M < 4096 || !(hi >= 4 * lo || (lo <= 96 && hi >= 256)))
+      return false;
+  }
   if (g.Ci % 8 || g.Co % 8 || g.ldi % 8 || ldy % 8) return false;
   if (g.kd > 255 || g.kh > 255 || g.kw > 255) return false;
   const int64_t xbytes = (int64_t)g.N * g.Di * g.Hi * g.Wi * g.ldi * 2, ybytes = (int64_t)g.M * ldy * 2;
@@ -323,13 +354,21 @@ void vc_wgrad8_plan(const ConvGeom& g, size_t det_capacity, bool det, int* split
 }
 
 void vc_wgrad8_launch(const ConvGeom& g, const void* x, const void* dy, int ldy, float* dw, int splits, int m_per_split,
-                      size_t split_stride, hipStream_t stream) {
+                      size_t split_stride, float* dbias, hipStream_t stream) {
   int tco, tcol;
   wgrad8_tile(g, &tco, &tcol);
   const int tiles_col = ceil_div(g.K, tcol), ntiles = ceil_div(g.Co, tco) * tiles_col;
 #define VC_W8(NI_, NJ_, WN_, WM_)                                                                                      \
-  hipLaunchKernelGGL((igemm_tn_wgrad8_kernel<NI_, NJ_, WN_, WM_>), dim3(ntiles * splits), dim3(NW8), 0, stream, g,     \
-                     (const bf16*)x, (const bf16*)dy, ldy, dw, m_per_split, ntiles, tiles_col, split_stride)
+  do {                                                                                                                 \
+    if (dbias)                                                                                                         \
+      hipLaunchKernelGGL((igemm_tn_wgrad8_kernel<NI_, NJ_, WN_, WM_, true>), dim3(ntiles * splits), dim3(NW8), 0,      \
+                         stream, g, (const bf16*)x, (const bf16*)dy, ldy, dw, m_per_split, ntiles, tiles_col,          \
+                         split_stride, dbias);                                                                         \
+    else                                                                                                               \
+      hipLaunchKernelGGL((igemm_tn_wgrad8_kernel<NI_, NJ_, WN_, WM_, false>), dim3(ntiles * splits), dim3(NW8), 0,     \
+                         stream, g, (const bf16*)x, (const bf16*)dy, ldy, dw, m_per_split, ntiles, tiles_col,          \
+                         split_stride, nullptr);                                                                       \
+  } while (0)
   if (tco == 256 && tcol == 256) VC_W8(8, 4, 2, 4);
   else if (tco == 256 && tcol == 128) VC_W8(4, 4, 4, 2);
   else if (tco == 128 && tcol == 256) VC_W8(4, 4, 2, 4);
