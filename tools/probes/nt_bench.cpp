@@ -159,13 +159,14 @@ int main(int argc, char** argv) {
       fflush(stdout);
     }
     if (!getenv("NTB_PASS") || atoi(getenv("NTB_PASS")) == 2) {  // weight gradient: 256-wide tiles against 128-wide
-      float *dw0, *dw1, *dwn; float ms[2] = {0, 0};
+      float *dw0, *dw1, *dwn, *db = nullptr; float ms[2] = {0, 0};
       HIP(hipMalloc(&dw0, nw * 4)); HIP(hipMalloc(&dw1, nw * 4)); HIP(hipMalloc(&dwn, nw * 4));
+      if (getenv("NTB_BIAS")) { HIP(hipMalloc(&db, l.Co * 4)); HIP(hipMemset(db, 0, l.Co * 4)); }  // with the bias gradient
       for (int variant = 0; variant < 2; ++variant) {
         setenv("VC_WGRAD8", variant == 0 ? "1" : "0", 1);
         float* o = variant == 0 ? dw0 : dw1;
         auto run = [&]() {
-          int rc = vc_conv_wgrad(desc, 1, x, 0, dy, 0, o, nullptr, 0, nullptr);
+          int rc = vc_conv_wgrad(desc, 1, x, 0, dy, 0, o, db, 0, nullptr);
           if (rc) { printf("%s wgrad failed: %s\n", l.name, vc_last_error()); exit(3); }
         };
         run();
@@ -198,7 +199,7 @@ int main(int argc, char** argv) {
       printf("%-10s %-28s %8.1f | %-7s %8.3f %8.0f | %8.3f %8.0f | %9.2e %9.2e\n", l.name, shape, gf, "wgrad", ms[0], gf / ms[0],
              ms[1], gf / ms[1], d[0] / (d[1] > 0 ? d[1] : 1), dn[0] / (dn[1] > 0 ? dn[1] : 1));
       fflush(stdout);
-      (void)hipFree(dw0); (void)hipFree(dw1); (void)hipFree(dwn);
+      (void)hipFree(dw0); (void)hipFree(dw1); (void)hipFree(dwn); if (db) (void)hipFree(db);
     }
     (void)hipFree(x); (void)hipFree(dy); (void)hipFree(wf); (void)hipFree(wt); (void)hipFree(y0); (void)hipFree(y1); (void)hipFree(dx0); (void)hipFree(dx1); (void)hipFree(yn);
   }

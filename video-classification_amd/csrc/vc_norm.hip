@@ -1281,8 +1281,16 @@ int vc_layernorm_bwd_add(int dtype, const void* x, const void* dout, const float
   VC_CHECK_SHAPE(C % 8 == 0 && C <= 2048 && M > 0, "vc_layernorm_bwd: need C %% 8 == 0 and C <= 2048 (C=%d)", C);
   // lanes per row / chunks per lane: (16,1) C<=128, (32,1) C<=256, (64,1) C<=512, (64,2) C<=1024, (64,4) C<=2048
   const int lpr = C <= 128 ? 16 : (C <= 256 ? 32 : 64);
+  // Blocks: at most `target`, of at least 64 rows.  A block ends with a fold of its dgamma / dbeta sums (LDS atomics of
+  // every lane, then 2 C global atomics), which costs more than the latency that more blocks would hide: with blocks
+  // of 16 rows (1568 - 6272 blocks per launch) the Swin-RNN step went 15.97 -> 16.56 ms.
+  static const int target = [] {
+    const char* e = getenv("VC_LN_BWD_BLOCKS");
+    const int n = e ? atoi(e) : 0;
+    return n > 0 ? n : 1024;
+  }();
   int rows_per_block = 64;
-  while (ceil_div(M, rows_per_block) > 1024) rows_per_block *= 2;
+  while (ceil_div(M, rows_per_block) > target) rows_per_block *= 2;
   dim3 grid(ceil_div(M, rows_per_block));
   // deterministic mode: a copy of dgamma / dbeta per block, added in block order afterwards (and one [2][C] slice of
   // LDS per row group of a block: 256 / lpr of them, at most 24 KiB)
