@@ -323,9 +323,16 @@ bool vc_wgrad8_eligible(const ConvGeom& g, int ldy, bool with_bias) {
   int tco, tcol;
   wgrad8_tile(g, &tco, &tcol);
   if (!wgrad8_has(tco, tcol)) return false;
+  if (policy == 1) return true;
+  // one workgroup per CU and slices of at least 512 rows: a short matrix (the LSTM and decoder layers, 512 rows) would
+  // leave most of the chip idle (CRNN step 5.78 -> 5.69 ms with them on the 128-wide kernel)
+  const int ntiles = ceil_div(g.Co, tco) * ceil_div(g.K, tcol), cus = vc_device_cus();
+  int slices = cus / ntiles > 0 ? cus / ntiles : 1;
+  if (slices > (g.M / 512 > 1 ? g.M / 512 : 1)) slices = g.M / 512 > 1 ? g.M / 512 : 1;
+  if (2 * ntiles * slices < cus) return false;
   // measured against the 128-wide kernel on the ResNet-50 layer table (512 frames): faster or equal on every shape
   // except 3 x 3 layers with 64 output channels (0.30 against 0.26 ms)
-  return policy == 1 || !(tco == 64 && g.kd * g.kh * g.kw > 1);
+  return !(tco == 64 && g.kd * g.kh * g.kw > 1);
 }
 
 // splits: slices of the pixel rows; m_per_split a multiple of 64, or 0 for interleaved slices.  One workgroup per CU and launch where the layer
