@@ -284,6 +284,15 @@ BENCH_GEOMETRIES = [
     ("l4_3x3_512_512", 512, 1, 7, 7, 512, 512, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     ("stem_unfolded_7x1_24_64", 512, 1, 224, 112, 24, 64, (1, 7, 1), (1, 2, 1), (0, 3, 0)),
     ("conv3d_layer2_32_64", 32, 16, 56, 56, 32, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    # fewer source channels than a k-tile is deep (8 / 16 / 32) under several filter taps: the width-unfolded first
+    # layers of Conv3D and EncoderCNN, EncoderCNN's second layer, and ragged small ones (odd tap counts, channel and
+    # row tails)
+    ("conv3d_layer1_unfolded_8_32", 32, 16, 112, 112, 8, 32, (3, 3, 1), (1, 1, 1), (1, 1, 0)),
+    ("cnn_layer1_unfolded_16_32", 512, 1, 224, 110, 16, 32, (1, 5, 1), (1, 2, 1), (0, 0, 0)),
+    ("cnn_layer2_32_64", 512, 1, 110, 110, 32, 64, (1, 3, 3), (1, 2, 2), (0, 0, 0)),
+    ("taps18_ragged_16_40", 3, 2, 13, 11, 16, 40, (2, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("taps27_ragged_8_136", 2, 5, 9, 7, 8, 136, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    ("taps25_s2_32_72", 3, 1, 21, 17, 32, 72, (1, 5, 5), (1, 2, 2), (0, 2, 2)),
 ]
 
 
@@ -324,7 +333,7 @@ def test_mfma_kernels_at_bench_geometries(cuda, case):
         assert _rel(part[:, 0], ys.sum(1)) < 1e-5 and _rel(part[:, 1], (ys * ys).sum(1)) < 1e-5
         del yb, part, ys
     del y, yn
-    if "stem" not in name:  # the network's first layer has no data gradient
+    if "stem" not in name and "unfolded" not in name:  # a network's first layer has no data gradient
         dx = torch.empty(N, D, H, W, Ci, device=cuda, dtype=torch.float32)
         dxn = torch.full_like(dx, float("nan"))
         L.call("vc_conv_dgrad", d, 1, L.ptr(dy), 0, L.ptr(wt), L.ptr(dx), 0, 1, 0, L.stream())
