@@ -806,19 +806,48 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
     for (int i = 0; i < 8; ++i) pg[k][i] = pb[k][i] = 0.f;
     if (cc < C8) ga[k] = load8(gamma + cc * 8);
   }
+  // The rows of the NEXT row group are requested before the current one is worked on (PF: up to two chunks per lane;
+  // beyond that the registers do not hold two groups): a lane has two batches of loads in flight instead of one, which
+  // matters where a launch is 1-2 blocks per CU (the 25088 x 384 tensors of Swin stage 3).
+  constexpr bool PF = NCH <= 2;
+  F8 xn[NCH], dn[NCH], an[NCH];
+  float mun = 0.f, rsn = 0.f;
+  auto fetch = [&](int rb) {
+    const int row = rb + rsl;
+    const bool lv = row < r1;
+    const size_t ro = (size_t)(lv ? row : r0) * C;
+    mun = mean[lv ? row : r0];
+    rsn = rstd[lv ? row : r0];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int cc = sub + LPR * k;
+      if (cc < C8) {
+        xn[k] = load8(x + ro + cc * 8);
+        dn[k] = load8(dout + ro + cc * 8);
+        if (add) an[k] = load8(add + ro + cc * 8);
+      }
+    }
+  };
+  if (PF && r0 < r1) fetch(r0);
   for (int rb = r0; rb < r1; rb += RPB) {  // uniform trip count: every lane joins the shuffles
     const int row = rb + rsl;
     const bool live = row < r1;
     const size_t ro = (size_t)(live ? row : r0) * C;
-    const float mu = mean[live ? row : r0], rs = rstd[live ? row : r0];
-    F8 xv[NCH], dv[NCH];
+    if (!PF) fetch(rb);
+    const float mu = mun, rs = rsn;
+    F8 xv[NCH], dv[NCH], av[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      xv[k] = xn[k];
+      dv[k] = dn[k];
+      av[k] = an[k];
+    }
+    if (PF && rb + RPB < r1) fetch(rb + RPB);
     float a = 0.f, b = 0.f;
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
       const int cc = sub + LPR * k;
       if (cc < C8) {
-        xv[k] = load8(x + ro + cc * 8);
-        dv[k] = load8(dout + ro + cc * 8);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const float xh = (xv[k].v[i] - mu) * rs, dg = dv[k].v[i] * ga[k].v[i];
@@ -843,9 +872,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ x, co
 #pragma unroll
           for (int i = 0; i < 8; ++i) o.v[i] = rs * (dv[k].v[i] * ga[k].v[i] - a - xv[k].v[i] * b);
           if (add) {  // gradient that reaches x past the normalisation (the residual stream)
-            const F8 r = load8(add + ro + cc * 8);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) o.v[i] += r.v[i];
+            for (int i = 0; i < 8; ++i) o.v[i] += av[k].v[i];
           }
           store8(dx + ro + cc * 8, o);
         }
