@@ -1,0 +1,19 @@
+set -e
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/m_r3g
+mkdir -p $O
+cd $R
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
+timeout -k 10 400 python bench.py > $O/bench_default.json 2> $O/bench_default.err
+for m in crnn conv3d swinrnn clusterswin; do
+  timeout -k 10 300 python bench.py --model $m > $O/bench_$m.json 2> $O/bench_$m.err
+done
+timeout -k 10 300 python bench.py --arch resnet152 --lstm-layers 3 --no-cpu-baseline > $O/bench_resnet152.json 2> $O/bench_resnet152.err
+for m in swinrnn clusterswin; do
+  timeout -k 10 300 python bench.py --model $m --batch 32 --no-cpu-baseline > $O/bench_${m}_b32.json 2> $O/bench_${m}_b32.err
+done
+bash tools/pmc_bench.sh gpurun_out/m_r3g/pmc_hbm
+python tools/hbm_traffic.py $O/pmc_hbm $O/hbm_traffic.json > /dev/null
+find $O -name "*.csv" -path "*pmc*" -delete
+find $O -type d -empty -delete
+echo final-measured
