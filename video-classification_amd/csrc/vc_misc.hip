@@ -52,58 +52,69 @@ __global__ void clip_to_cl_kernel(const float* __restrict__ x, T* __restrict__ o
 // so the layer becomes a (kd, kh, 1) convolution with stride (sd, sh, 1) over Jp = pad8(kw*C) channels.
 // Source layouts and frame order as for clip_to_cl_kernel.
 // ---------------------------------------------------------------------------
-// One block per (frame, image row): the C source rows are read coalesced into LDS once, then every thread
-// assembles the Jp values of its output pixels from LDS and writes them as 16-byte vectors.
+// One block per `rpb` consecutive (frame, image row) pairs: their C source rows each are read coalesced into LDS
+// first (all loads of the block in flight together: with one row per block a CU held 21 KiB of requests and the pass
+// ran at half the copy bandwidth), then every thread assembles the Jp values of its output pixels from LDS and writes
+// them as 16-byte vectors.
 template <typename T>
 __global__ void clip_unfold_w_kernel(const float* __restrict__ x, T* __restrict__ out, int B, int Tn, int C, int H,
-                                     int W, int Wo, int kw, int sw, int pw, int Jp, int time_major, int chan_outer) {
-  extern __shared__ __attribute__((aligned(16))) float srow[];  // [C][W]
+                                     int W, int Wo, int kw, int sw, int pw, int Jp, int time_major, int chan_outer,
+                                     int rows, int rpb) {
+  extern __shared__ __attribute__((aligned(16))) float srow[];  // [rpb][C][W]
   const int S = H * W;
-  const int fh = blockIdx.x;       // frame * H + h
-  const int h = fh % H, f = fh / H;
-  int b, t;
-  if (time_major) {
-    t = f / B;
-    b = f - t * B;
-  } else {
-    b = f / Tn;
-    t = f - b * Tn;
-  }
-  for (int c = 0; c < C; ++c) {  // one source row per channel, 16-byte loads where the row allows
+  const int fh0 = blockIdx.x * rpb;
+  const int nr = min(rpb, rows - fh0);
+  for (int rc = 0; rc < nr * C; ++rc) {  // one source row per (image row, channel), 16-byte loads where it allows
+    const int r = rc / C, c = rc - r * C;
+    const int fh = fh0 + r;
+    const int h = fh % H, f = fh / H;
+    int b, t;
+    if (time_major) {
+      t = f / B;
+      b = f - t * B;
+    } else {
+      b = f / Tn;
+      t = f - b * Tn;
+    }
     const float* row = x + (chan_outer ? (((size_t)b * C + c) * Tn + t) * S : (((size_t)b * Tn + t) * C + c) * S) +
                        (size_t)h * W;
+    float* dst = srow + rc * W;
     if ((W & 3) == 0 && (reinterpret_cast<uintptr_t>(row) & 15) == 0) {
       for (int i = threadIdx.x; i < (W >> 2); i += blockDim.x)
-        reinterpret_cast<f32x4*>(srow + c * W)[i] = reinterpret_cast<const f32x4*>(row)[i];
+        reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(row)[i];
     } else {
-      for (int i = threadIdx.x; i < W; i += blockDim.x) srow[c * W + i] = row[i];
+      for (int i = threadIdx.x; i < W; i += blockDim.x) dst[i] = row[i];
     }
   }
   __syncthreads();
   const int J8 = Jp >> 3, kwc = kw * C;
-  // one 8-channel chunk of one output pixel per step; the (tap, channel) of the chunk's first element is found by
-  // counting, so that the loop has no integer divisions
-  for (int wo = threadIdx.x / J8, ch = threadIdx.x - wo * J8; wo < Wo;) {
-    int q = ch * 8, j = q / C, c = q - j * C;
-    const int w0 = wo * sw - pw;
-    F8 v;
+  for (int r = 0; r < nr; ++r) {
+    const int fh = fh0 + r;
+    const float* sr = srow + r * C * W;
+    // one 8-channel chunk of one output pixel per step; the (tap, channel) of the chunk's first element is found by
+    // counting, so that the loop has no integer divisions
+    for (int wo = threadIdx.x / J8, ch = threadIdx.x - wo * J8; wo < Wo;) {
+      int q = ch * 8, j = q / C, c = q - j * C;
+      const int w0 = wo * sw - pw;
+      F8 v;
 #pragma unroll
-    for (int e = 0; e < 8; ++e, ++q) {
-      float val = 0.f;
-      if (q < kwc && (unsigned)(w0 + j) < (unsigned)W) val = srow[c * W + w0 + j];
-      v.v[e] = val;
-      if (++c == C) {
-        c = 0;
-        ++j;
+      for (int e = 0; e < 8; ++e, ++q) {
+        float val = 0.f;
+        if (q < kwc && (unsigned)(w0 + j) < (unsigned)W) val = sr[c * W + w0 + j];
+        v.v[e] = val;
+        if (++c == C) {
+          c = 0;
+          ++j;
+        }
       }
-    }
-    store8(out + ((size_t)fh * Wo + wo) * Jp + ch * 8, v);
-    // advance by blockDim.x chunks
-    ch += blockDim.x % J8;
-    wo += blockDim.x / J8;
-    if (ch >= J8) {
-      ch -= J8;
-      ++wo;
+      store8(out + ((size_t)fh * Wo + wo) * Jp + ch * 8, v);
+      // advance by blockDim.x chunks
+      ch += blockDim.x % J8;
+      wo += blockDim.x / J8;
+      if (ch >= J8) {
+        ch -= J8;
+        ++wo;
+      }
     }
   }
 }
@@ -193,6 +204,59 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __re
       }
     }
     store8(dx + i * 8, acc);
+  }
+}
+
+// The ResNet stem's pool (3 x 3, stride 2, padding 1, even H and W) backward: a thread owns the 2 x 2 input pixels
+// (2a .. 2a+1, 2b .. 2b+1) of one 8-channel chunk.  They lie in the four windows (a, b), (a, b+1), (a+1, b), (a+1, b+1)
+// only, each read once (the per-pixel form above reads 9 windows for the same four pixels), and every pixel's taps in
+// those windows are constants: (2a, 2b) is tap 4 of (a, b); (2a, 2b+1) taps 5 / 3 of (a, b) / (a, b+1); (2a+1, 2b) taps
+// 7 / 1 of (a, b) / (a+1, b); (2a+1, 2b+1) taps 8 / 6 / 2 / 0 of the four.
+template <typename T>
+__global__ void maxpool_bwd_3s2p1_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx, T* __restrict__ dx,
+                                         int N, int Ho, int Wo, int C8) {
+  const int64_t total = (int64_t)N * Ho * Wo * C8;
+  const int H = 2 * Ho, W = 2 * Wo;
+  for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (int64_t)gridDim.x * blockDim.x) {
+    const int cc = (int)(it % C8);
+    int64_t t = it / C8;
+    const int b = (int)(t % Wo);
+    t /= Wo;
+    const int a = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    const bool hb = b + 1 < Wo, ha = a + 1 < Ho;
+    const size_t o00 = ((((size_t)n * Ho + a) * Wo + b) * C8 + cc) * 8;
+    const size_t o01 = o00 + (size_t)C8 * 8, o10 = o00 + (size_t)Wo * C8 * 8, o11 = o10 + (size_t)C8 * 8;
+    F8 d[4];
+    uint2 w[4];
+    const F8 zero = {{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
+    const uint2 none = {0xFFFFFFFFu, 0xFFFFFFFFu};  // no tap has index 255
+    d[0] = load8(dy + o00);
+    w[0] = *reinterpret_cast<const uint2*>(idx + o00);
+    d[1] = hb ? load8(dy + o01) : zero;
+    w[1] = hb ? *reinterpret_cast<const uint2*>(idx + o01) : none;
+    d[2] = ha ? load8(dy + o10) : zero;
+    w[2] = ha ? *reinterpret_cast<const uint2*>(idx + o10) : none;
+    d[3] = (ha && hb) ? load8(dy + o11) : zero;
+    w[3] = (ha && hb) ? *reinterpret_cast<const uint2*>(idx + o11) : none;
+    F8 p00, p01, p10, p11;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int tp[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) tp[k] = (int)(((j < 4 ? w[k].x : w[k].y) >> (8 * (j & 3))) & 0xff);
+      p00.v[j] = tp[0] == 4 ? d[0].v[j] : 0.f;
+      p01.v[j] = (tp[0] == 5 ? d[0].v[j] : 0.f) + (tp[1] == 3 ? d[1].v[j] : 0.f);
+      p10.v[j] = (tp[0] == 7 ? d[0].v[j] : 0.f) + (tp[2] == 1 ? d[2].v[j] : 0.f);
+      // the same order of additions as the per-pixel form (windows by row, then by column)
+      p11.v[j] = (((tp[0] == 8 ? d[0].v[j] : 0.f) + (tp[1] == 6 ? d[1].v[j] : 0.f)) + (tp[2] == 2 ? d[2].v[j] : 0.f)) +
+                 (tp[3] == 0 ? d[3].v[j] : 0.f);
+    }
+    const size_t i00 = ((((size_t)n * H + 2 * a) * W + 2 * b) * C8 + cc) * 8;
+    store8(dx + i00, p00);
+    store8(dx + i00 + (size_t)C8 * 8, p01);
+    store8(dx + i00 + (size_t)W * C8 * 8, p10);
+    store8(dx + i00 + (size_t)W * C8 * 8 + (size_t)C8 * 8, p11);
   }
 }
 
@@ -528,9 +592,18 @@ int vc_clip_unfold_w(int dtype, const float* x, void* out, int B, int T_, int C,
   const int Wo = (W + 2 * pw - kw) / sw + 1;
   const int64_t rows = (int64_t)B * T_ * H;
   VC_CHECK_SHAPE(rows < (1ll << 31) && (size_t)C * W * sizeof(float) <= 48 * 1024, "vc_clip_unfold_w: image too large");
+  static const int rpb_env = [] {
+    const char* e = getenv("VC_UNFOLD_ROWS");
+    const int n = e ? atoi(e) : 0;
+    return n > 0 ? n : 4;
+  }();
+  int rpb = rpb_env;  // image rows per block: as many as 16 KiB of LDS hold (eight blocks per CU), at most rpb_env
+  while (rpb > 1 && (size_t)rpb * C * W * sizeof(float) > 16 * 1024) rpb >>= 1;
+  const size_t lds = (size_t)rpb * C * W * sizeof(float);
+  const unsigned blocks = (unsigned)((rows + rpb - 1) / rpb);
   DISPATCH_T(dtype, "vc_clip_unfold_w",
-             hipLaunchKernelGGL((clip_unfold_w_kernel<T>), dim3((unsigned)rows), dim3(NTHR), (size_t)C * W * sizeof(float),
-                                stream, x, (T*)out, B, T_, C, H, W, Wo, kw, sw, pw, Jp, time_major, chan_outer);)
+             hipLaunchKernelGGL((clip_unfold_w_kernel<T>), dim3(blocks), dim3(NTHR), lds, stream, x, (T*)out, B, T_, C, H,
+                                W, Wo, kw, sw, pw, Jp, time_major, chan_outer, (int)rows, rpb);)
   VC_LAUNCH_CHECK("vc_clip_unfold_w");
   return VC_OK;
 }
@@ -554,6 +627,14 @@ int vc_maxpool2d_bwd(int dtype, const void* dy, const uint8_t* idx, void* dx, in
   VC_CHECK_SHAPE(C % 8 == 0 && k > 0 && s > 0 && p >= 0 && p < k, "vc_maxpool2d_bwd: bad shape");
   const int Ho = (H + 2 * p - k) / s + 1, Wo = (W + 2 * p - k) / s + 1;
   VC_CHECK_SHAPE(H <= 65535 && N <= 65535, "vc_maxpool2d_bwd: at most 65535 rows and samples");
+  if (k == 3 && s == 2 && p == 1 && H % 2 == 0 && W % 2 == 0) {
+    const int64_t total = (int64_t)N * Ho * Wo * (C / 8);
+    DISPATCH_T(dtype, "vc_maxpool2d_bwd",
+               hipLaunchKernelGGL((maxpool_bwd_3s2p1_kernel<T>), dim3(ew_grid(total)), dim3(NTHR), 0, stream, (const T*)dy,
+                                  idx, (T*)dx, N, Ho, Wo, C / 8);)
+    VC_LAUNCH_CHECK("vc_maxpool2d_bwd");
+    return VC_OK;
+  }
   const dim3 grid(ceil_div(W * (C / 8), NTHR), H, N);
   DISPATCH_T(dtype, "vc_maxpool2d_bwd",
              hipLaunchKernelGGL((maxpool_bwd_kernel<T>), grid, dim3(NTHR), 0, stream, (const T*)dy, idx, (T*)dx, N, H, W,
