@@ -309,7 +309,9 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_fast_kernel(ConvGeom g, cons
 // source, both computed once per output tile; per filter tap a row costs an add and a select, inside a tap
 // nothing at all (the k-tile's advance is the instruction's scalar offset).  Needs at most 32 filter taps, a
 // stride-1 gather in MODE 1 and operands of less than 4 GiB.
-template <int MODE, int TN_, int EPI = EPI_NONE, bool BL = false, int NA = 3>
+// BM_ = 256 (with TN_ = 64): the four waves stack along the pixel rows, each with all 64 channels of a 64-row slab,
+// instead of two by two with 32 channels each: a wave's epilogue then writes whole 128-byte rows of a 64-channel tensor.
+template <int MODE, int TN_, int EPI = EPI_NONE, bool BL = false, int NA = 3, int BM_ = 128>
 __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, const bf16* __restrict__ src,
                                                                    const bf16* __restrict__ wgt,
                                                                    const float* __restrict__ bias,
@@ -321,16 +323,19 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
   // NA staged k-tiles of the source rows and two of the weight rows.  NA = 3 keeps one source k-tile in flight ACROSS
   // the barrier (a counted vmcnt leaves its loads outstanding): the source streams from HBM, whose latency under load
   // is several times one k-tile of products; the weights come out of L2 and get by with one k-tile of lead.
-  constexpr int ASZ = BM * BK, WSZ = TN_ * BK;  // elements per staged k-tile
+  constexpr bool TALL = BM_ == 256;
+  static_assert(BM_ == 128 || (TALL && TN_ == 64 && NA == 2), "tile rows");
+  constexpr int NAR = BM_ / 32;                  // source rows staged per thread
+  constexpr int ASZ = BM_ * BK, WSZ = TN_ * BK;  // elements per staged k-tile
   __shared__ __attribute__((aligned(1024))) bf16 smem[NA * ASZ + 2 * WSZ];
   bf16* const sA0 = smem;
   bf16* const sW0 = smem + NA * ASZ;
-  constexpr int WI = TN_ / 32;   // 16-channel tiles per wave
+  constexpr int WI = TALL ? TN_ / 16 : TN_ / 32;   // 16-channel tiles per wave
   constexpr int NWROW = TN_ / 32;  // weight rows staged per thread
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = TALL ? wave : wave >> 1, wn = TALL ? 0 : wave & 1;
   const int tiles_n = (g.Co + TN_ - 1) / TN_;
   int vblock;
   xcd_remap(vblock);
@@ -377,21 +382,21 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
   KCursor ca{vblock, 0, 0, 0, 0, 0, 0}, cw = ca;
 
   // ---- staging by global LDS-DMA loads ----
-  RowPos rp[4];
-  const bf16* ap[4];
+  RowPos rp[NAR];
+  const bf16* ap[NAR];
   const bf16* wp[4];
-  int ainc[4], winc[4];
+  int ainc[NAR], winc[4];
 
   auto stage_a_gl = [&](bf16* sA, KCursor& c) {
     if (c.kt == 0) {  // first k-tile of an output tile: its rows
-      const int m0 = (unit_tile(c.tile) / tiles_n) * BM;
+      const int m0 = (unit_tile(c.tile) / tiles_n) * BM_;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) rp[i] = decode_row<MODE>(g, m0 + lrow + 32 * i);
+      for (int i = 0; i < NAR; ++i) rp[i] = decode_row<MODE>(g, m0 + lrow + 32 * i);
     }
     if (c.cb == 0) {
       const int koff = unit_koff(c.tile);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NAR; ++i) {
         const int pix = gather_pixel<MODE>(g, rp[i], c.rd, c.rh, c.rw);
         const bool ok = pix >= 0;
 #ifdef VC_ABL_HOTA  // ablation build: source rows from a 64 KiB window (time only)
@@ -404,9 +409,9 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
     }
     const bool dead = ktail && c.cb * BK + lchunk * 8 >= g.Ci;  // this thread's chunk of a partial last k-tile
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(dead ? zero : ap[i], sA + (32 * i + 8 * wave) * BK);
+    for (int i = 0; i < NAR; ++i) glds16(dead ? zero : ap[i], sA + (32 * i + 8 * wave) * BK);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ap[i] += ainc[i];
+    for (int i = 0; i < NAR; ++i) ap[i] += ainc[i];
     advance(c);
   };
   auto stage_w_gl = [&](bf16* sW, KCursor& c) {
@@ -440,7 +445,7 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
 
   // ---- staging by buffer LDS-DMA loads (see the comment above the kernel) ----
   constexpr unsigned SENT = 0xFFFFFFF0u;  // beyond every descriptor's range
-  unsigned abase[4], amask[4], avo[4], wvo[NWROW];
+  unsigned abase[NAR], amask[NAR], avo[NAR], wvo[NWROW];
   int s_wk = 0;  // uniform: byte offset of the current tap's weights in a packed row
   const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<bf16*>(src), 0, (int)((unsigned)(g.N * g.Di * g.Hi * g.Wi) * (unsigned)g.ldi * 2u), 0x00020000);
@@ -449,9 +454,9 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
 
   auto stage_a_bl = [&](bf16* sA, KCursor& c) {
     if (c.kt == 0) {
-      const int m0 = (c.tile / tiles_n) * BM;
+      const int m0 = (c.tile / tiles_n) * BM_;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NAR; ++i) {
         const RowPos r = decode_row<MODE>(g, m0 + lrow + 32 * i);  // rows beyond M: coordinates far outside
         abase[i] = (unsigned)((((r.n * g.Di + r.d0) * g.Hi + r.h0) * g.Wi + r.w0) * g.ldi * 2 + lchunk * 16);
         amask[i] = tap_mask<MODE>(g, r);
@@ -461,12 +466,12 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
       int toff = ((c.rd * g.Hi + c.rh) * g.Wi + c.rw) * g.ldi * 2;
       if (MODE != 0) toff = -toff;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) avo[i] = ((amask[i] >> c.tap) & 1u) ? abase[i] + (unsigned)toff : SENT;
+      for (int i = 0; i < NAR; ++i) avo[i] = ((amask[i] >> c.tap) & 1u) ? abase[i] + (unsigned)toff : SENT;
     }
     const int kb = c.cb * (BK * 2);  // byte advance inside the tap: the instructions' scalar offset
     const bool dead = ktail && c.cb * BK + lchunk * 8 >= g.Ci;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NAR; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(sA + (32 * i + 8 * wave) * BK), 16,
                                                (int)(dead ? SENT : avo[i]), kb, 0, 0);
     advance(c);
@@ -544,9 +549,9 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
       const int tile_m = rt / tiles_n, tile_n = rt - tile_m * tiles_n;
       if (KS > 1) {  // this slice's fp32 partial; bias and activation belong to the pass that adds the slices
         float* part = reinterpret_cast<float*>(out) + (size_t)(c_tile - rt * KS) * g.M * g.ldc;
-        nt_epilogue<MODE, WI>(g, acc, tile_m * BM, tile_n * TN_, wm, wn, lane, nullptr, part, 0, 1, 0);
+        nt_epilogue<MODE, WI>(g, acc, tile_m * BM_, tile_n * TN_, wm, wn, lane, nullptr, part, 0, 1, 0);
       } else if (out_f32) {
-        nt_epilogue<MODE, WI>(g, acc, tile_m * BM, tile_n * TN_, wm, wn, lane, bias, out, relu, out_f32, beta);
+        nt_epilogue<MODE, WI>(g, acc, tile_m * BM_, tile_n * TN_, wm, wn, lane, bias, out, relu, out_f32, beta);
       } else {
         // the k-tile that was just multiplied is free once every wave has finished reading it (LDS reads only:
         // the stages in flight keep streaming while the tile is written out); a wave's private image of its part
@@ -557,11 +562,11 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
         // two copies of the epilogue: a bias load (to registers) makes the compiler wait for every load in flight,
         // the staged k-tiles included, and a shared copy would wait on the bias-free path too
         if (bias || (EPI != EPI_NONE && EPI != EPI_BN_TAIL))  // (the other epilogues are register-bound: one copy)
-          nt_epilogue_lds<MODE, WI, EPI, true>(g, acc, tile_m * BM, tile_n * TN_, wm, wn, lane, bias,
+          nt_epilogue_lds<MODE, WI, EPI, true>(g, acc, tile_m * BM_, tile_n * TN_, wm, wn, lane, bias,
                                                reinterpret_cast<bf16*>(out), relu, beta, img, bn_partial, tail_y,
                                                tail_bits);
         else
-          nt_epilogue_lds<MODE, WI, EPI, false>(g, acc, tile_m * BM, tile_n * TN_, wm, wn, lane, nullptr,
+          nt_epilogue_lds<MODE, WI, EPI, false>(g, acc, tile_m * BM_, tile_n * TN_, wm, wn, lane, nullptr,
                                                 reinterpret_cast<bf16*>(out), relu, beta, img, bn_partial, tail_y,
                                                 tail_bits);
       }
@@ -1410,13 +1415,20 @@ int nt_ring() {
   return v;
 }
 
+// Layers of up to 64 output channels run on 256 x 64 tiles (measured on the 56 x 56 ResNet layers: 4-8 % faster than
+// 128 x 64, forward and data gradient); VC_NT_TALL=0 keeps the 128 x 64 tile (read at every call: A/B measurements)
+int nt_tall() {
+  const char* e = getenv("VC_NT_TALL");
+  return e ? atoi(e) : 1;
+}
+
 // geometries the buffer-load staging covers (see igemm_nt_persist_kernel)
-bool bl_eligible(const ConvGeom& g, int mode) {
+bool bl_eligible(const ConvGeom& g, int mode, bool single_tap_too = false) {
   // Measured on the ResNet-50 layer table: 3x3 layers gain 4-18 % (forward 64 -> 64: 0.267 -> 0.256 ms, its data
   // gradient 0.301 -> 0.253 ms), single-tap layers lose 0-5 % (their tiles have no per-tap work to save), so those keep
   // the global-load staging unless VC_IGEMM_BL=2 forces the buffer form (tests, A/B runs).
   const int taps = g.kd * g.kh * g.kw;
-  if (!use_bl() || taps > 32 || (taps == 1 && use_bl() != 2)) return false;
+  if (!use_bl() || taps > 32 || (taps == 1 && use_bl() != 2 && !single_tap_too)) return false;
   if (mode == 1 && (g.sd != 1 || g.sh != 1 || g.sw != 1)) return false;
   const int64_t abytes = (int64_t)g.N * g.Di * g.Hi * g.Wi * g.ldi * 2, wbytes = (int64_t)g.Co * g.ldw * 2;
   return abytes < 0xFFFF0000ll && wbytes < 0xFFFF0000ll;
@@ -1463,7 +1475,15 @@ int launch_nt(const ConvGeom& g, int dtype, const void* src, const void* wgt, co
     if (nt_persist_eligible(g, dtype) && MODE != 2 && vc_nt8_eligible(g, MODE, out_f32, EPI_NONE)) {
       vc_nt8_launch(g, MODE, EPI_NONE, stream, src, wgt, bias, out, relu, beta, bn_partial, nullptr, nullptr);
     } else if (nt_persist_eligible(g, dtype)) {
-      if (g.Co <= nt_narrow()) {  // a 128-wide channel tile would be half padding
+      if (g.Co <= nt_narrow() && MODE != 2 && nt_tall() && !out_f32 && bl_eligible(g, MODE, true)) {
+        // 256 x 64 tiles, the waves stacked along the rows (buffer form only: the global-load form spills here)
+        const int t = ceil_div(g.M, 256) * ceil_div(g.Co, 64);
+        const int grid = t < nt_persist_blocks() ? t : nt_persist_blocks();
+        if constexpr (MODE != 2)
+          hipLaunchKernelGGL((igemm_nt_persist_kernel<MODE, 64, EPI_NONE, true, 2, 256>), dim3(grid), dim3(NTHR), 0,
+                             stream, g, (const bf16*)src, (const bf16*)wgt, bias, out, relu, out_f32, beta, t,
+                             bn_partial, (const bf16*)nullptr, (const uint8_t*)nullptr);
+      } else if (g.Co <= nt_narrow()) {  // a 128-wide channel tile would be half padding
         const int t64 = ceil_div(g.M, BM) * ceil_div(g.Co, 64);
         const int grid = t64 < nt_persist_blocks() * 3 / 2 ? t64 : nt_persist_blocks() * 3 / 2;
         launch_persist<MODE, 64, EPI_NONE>(g, grid, stream, src, wgt, bias, out, relu, out_f32, beta, t64, bn_partial,
@@ -1671,6 +1691,12 @@ int vc_conv_dgrad_bn_pre(const int* desc, int dtype, const void* dy, const void*
                  "vc_conv_dgrad_bn_pre: unsupported geometry (ask vc_conv_dgrad_bn_pre_supported)");
   if (vc_nt8_eligible(g, 1, 0, EPI_BN_PRE)) {
     vc_nt8_launch(g, 1, EPI_BN_PRE, stream, dy, w_packed_t, stat, dx, rows_per_group, 0, bn_partial, y, nullptr);
+  } else if (g.Co <= nt_narrow() && nt_tall() && bl_eligible(g, 1, true)) {
+    const int t = ceil_div(g.M, 256) * ceil_div(g.Co, 64);
+    const int grid = t < nt_persist_blocks() ? t : nt_persist_blocks();
+    hipLaunchKernelGGL((igemm_nt_persist_kernel<1, 64, EPI_BN_PRE, true, 2, 256>), dim3(grid), dim3(NTHR), 0, stream, g,
+                       (const bf16*)dy, (const bf16*)w_packed_t, stat, dx, rows_per_group, 0, 0, t, bn_partial,
+                       (const bf16*)y, (const uint8_t*)nullptr);
   } else if (g.Co <= nt_narrow()) {
     const int t64 = ceil_div(g.M, BM) * ceil_div(g.Co, 64);
     const int grid = t64 < nt_persist_blocks() * 3 / 2 ? t64 : nt_persist_blocks() * 3 / 2;
