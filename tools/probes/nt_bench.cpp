@@ -93,6 +93,8 @@ int main(int argc, char** argv) {
       {"lstm.ih", 512, 1, 1, 512, 2048, 1, 1, 0},
       // ResNet stem over row triples: 3 taps along H of 64 channels (3 rows x 7 taps x 3 colours)
       {"stem.rows", F, 112, 112, 64, 64, 3, 1, 1, 1},
+      // ResNet stem as it runs: width-unfolded, 7 taps along H (stride 2) of 24 channels
+      {"stem.unf", F, 224, 112, 24, 64, 7, 2, 3, 1},
   };
   std::vector<Layer> sel;
   for (auto& l : all) {

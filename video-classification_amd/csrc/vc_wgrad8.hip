@@ -331,8 +331,9 @@ bool vc_wgrad8_eligible(const ConvGeom& g, int ldy, bool with_bias) {
   if (slices > (g.M / 512 > 1 ? g.M / 512 : 1)) slices = g.M / 512 > 1 ? g.M / 512 : 1;
   if (2 * ntiles * slices < cus) return false;
   // measured against the 128-wide kernel on the ResNet-50 layer table (512 frames): faster or equal on every shape
-  // except 3 x 3 layers with 64 output channels (0.30 against 0.26 ms)
-  return !(tco == 64 && g.kd * g.kh * g.kw > 1);
+  // except 3 x 3 layers with 64 output channels (0.31 against 0.24 ms: three column tiles re-read dy); the unfolded
+  // stem (7 taps of 24 channels, one column tile) gains (0.423 against 0.458 ms)
+  return !(tco == 64 && g.kd * g.kh * g.kw > 1 && g.K > 256);
 }
 
 // splits: slices of the pixel rows; m_per_split a multiple of 64, or 0 for interleaved slices.  One workgroup per CU and launch where the layer
