@@ -518,6 +518,20 @@ __global__ __launch_bounds__(NTHR, 2) void igemm_nt_persist_kernel(ConvGeom g, c
   const int aoff = (wm * 64 + l15) * BK, woff = (wn * (WI * 16) + l15) * BK;
 
   auto compute = [&](const bf16* tA, const bf16* tW) {
+#ifdef VC_ABL_BNPRO  // ablation build (time only): relu(y * s + t) on the staged source k-tile, in place, before the
+    {                 // products -- what a BatchNorm apply folded into its consumer's operand path would cost
+      bf16* tAw = const_cast<bf16*>(tA);
+#pragma unroll
+      for (int i = 0; i < NAR; ++i) {
+        bf16x8* pv = reinterpret_cast<bf16x8*>(tAw + (32 * i + lrow) * BK + pchunk * 8);
+        bf16x8 v = *pv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (bf16)fmaxf(fmaf((float)v[e], 1.00390625f, 0.0009765625f * (float)(lchunk + e)), 0.f);
+        *pv = v;
+      }
+      lds_barrier();
+    }
+#endif
     // all fragments of the k-tile are requested before the first product, so that one LDS round trip is exposed
     // per k-tile instead of one per group of products
     bf16x8 wf[2][WI], af[2][4];
