@@ -23,6 +23,8 @@
 // which ends at the slice's last row.
 #include <stdlib.h>
 
+#include <stdio.h>
+
 #include "vc_igemm_dev.h"
 
 namespace {
@@ -297,6 +299,24 @@ int wgrad8_policy() {
 void wgrad8_tile(const ConvGeom& g, int* tco, int* tcol) {
   *tco = g.Co <= 64 ? 64 : g.Co <= 128 ? 128 : 256;
   *tcol = g.K <= 64 ? 64 : g.K <= 128 ? 128 : 256;
+  // 256 x 128 instead of 256 x 256 where both sides would be full: a slice then adds half the fp32 tile (the atomics of
+  // 256 workgroups x 256 KiB are 64 MB per launch, beside 250 MB of operands on the 14 x 14 1 x 1 layers), measured on
+  // the ResNet-50 table: 1 x 1 layers of stages 3-4 0.102 -> 0.086 ms, 3 x 3 at 14 x 14 0.154 -> 0.151; the 3 x 3 layers
+  // at 7 x 7 (25088 rows) lose (0.154 -> 0.162) and keep the full tile.  VC_WGRAD8_RULE=0 keeps 256 x 256 everywhere.
+  {
+    const char* r = getenv("VC_WGRAD8_RULE");
+    const int v = r ? atoi(r) : 1;
+    const bool short_multi_tap = g.kd * g.kh * g.kw > 1 && g.M < 50000;
+    if (*tco == 256 && *tcol == 256 && (v == 2 || (v == 1 && !short_multi_tap))) *tcol = 128;
+  }
+  // VC_WGRAD8_CAP=co,col caps the tile sides (A/B measurements: 256,128 or 128,256 halve the fp32 tile a slice adds)
+  if (const char* e = getenv("VC_WGRAD8_CAP")) {
+    int a = 0, b = 0;
+    if (sscanf(e, "%d,%d", &a, &b) == 2) {
+      if ((a == 128 || a == 64) && *tco > a) *tco = a;
+      if ((b == 128 || b == 64) && *tcol > b) *tcol = b;
+    }
+  }
 }
 bool wgrad8_has(int tco, int tcol) {  // the instantiated shapes
   return (tco == 256 && (tcol == 256 || tcol == 128 || tcol == 64)) || (tcol == 256 && (tco == 128 || tco == 64));
